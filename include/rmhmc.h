@@ -1,0 +1,166 @@
+/*
+ * rmhmc.h — C-ABI of the MI355X-native RMHMC hot path (librmhmc_hip.so).
+ *
+ * Drop-in boundary for the generalised-leapfrog RMHMC sampler of
+ * emilemathieu/RiemannHamiltonianMonteCarlo, code/rmhmc.py:13-201
+ * (Bayesian logistic regression, N(0, alpha I) prior).  The reference has no
+ * FFI of its own: its boundary is the in-process Python call
+ *     results_beta[i], results_time[i] = RMHMC(XX, t)        (code/main.py:52)
+ * so the entry points below are what a ctypes binding for that call would
+ * bind.  Every entry point cites the reference block it
+ * replaces.  The same symbols are exported by the CPU oracle
+ * (oracle/librmhmc_oracle.so), which is test infrastructure only.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - every function returns an int status: 0 = ok, <0 = error; the message is
+ *     available from rmhmc_last_error(ctx) (ctx may be NULL after a failed
+ *     rmhmc_create).
+ *   - all buffers are caller-owned HOST memory unless the name ends in _dev;
+ *     float64, row-major, chain-major: w[n_chains*D], G[n_chains*D*D] ...
+ *   - the context is opaque, owns all device memory, and is not thread-safe;
+ *     the library is re-entrant across contexts.
+ *   - arithmetic type: float64 (the reference is float64 throughout).
+ */
+#ifndef RMHMC_H
+#define RMHMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rmhmc_ctx rmhmc_ctx;
+
+/* status codes */
+#define RMHMC_OK 0
+#define RMHMC_ERR_INVALID (-1)     /* bad argument / call order                */
+#define RMHMC_ERR_NO_DEVICE (-2)   /* no HIP device / extension cannot run     */
+#define RMHMC_ERR_RUNTIME (-3)     /* HIP runtime error                        */
+#define RMHMC_ERR_UNSUPPORTED (-4) /* shape / dtype outside the built kernels  */
+#define RMHMC_ERR_NOMEM (-5)
+
+/* dtype enum (only float64 is built; the reference is float64) */
+#define RMHMC_F64 0
+
+/* flags for rmhmc_create.  RMHMC_COMPAT reproduces the Python reference
+ * bit-for-behaviour; clearing a bit gives the "corrected" variant. */
+#define RMHMC_FLAG_MOMENTUM_LT (1u << 0) /* p = L^T z, L lower (rmhmc.py:60,80);
+                                            cleared: p = L z, Cov(p) = G       */
+#define RMHMC_FLAG_GUARDS (1u << 1)      /* RENORMALIZE guards rmhmc.py:81-85,
+                                            125-130                            */
+#define RMHMC_COMPAT (RMHMC_FLAG_MOMENTUM_LT | RMHMC_FLAG_GUARDS)
+#define RMHMC_FLAG_ORACLE_LITERAL (1u << 8) /* oracle only: form the DxDxD
+                                               InvGdG tensor and use LU
+                                               inv/solve like rmhmc.py:64-77  */
+
+/* per-chain status bits written to status_out[] */
+#define RMHMC_ST_NOT_PD (1 << 0)       /* a Cholesky pivot was <=0 or NaN       */
+#define RMHMC_ST_NONFINITE (1 << 1)    /* w or p became inf/NaN                 */
+#define RMHMC_ST_GUARD_P (1 << 2)      /* momentum guard fired (rmhmc.py:81)    */
+#define RMHMC_ST_GUARD_W (1 << 3)      /* position guard fired (rmhmc.py:125)   */
+
+const char *rmhmc_version(void);
+
+/* Create a context for M data rows, D dimensions, n_chains independent chains
+ * on HIP device `device_id`.  Fails with RMHMC_ERR_NO_DEVICE when no GPU is
+ * usable (there is no CPU fallback in the product library). */
+int rmhmc_create(rmhmc_ctx **out, int32_t device_id, int64_t M, int32_t D,
+                 int64_t n_chains, int32_t dtype, uint32_t flags);
+void rmhmc_destroy(rmhmc_ctx *ctx);
+const char *rmhmc_last_error(const rmhmc_ctx *ctx);
+/* Human-readable device / build description into buf (NUL-terminated). */
+int rmhmc_device_info(rmhmc_ctx *ctx, char *buf, size_t len);
+
+/* Inputs of RMHMC(XX, t): XX float64 (M,D) C-contiguous, t float64 (M,) in
+ * {0,1}; alpha = prior variance (rmhmc.py:19, hard-coded 100 there).
+ * Borrowed for the duration of the call only (copied to HBM). */
+int rmhmc_set_data(rmhmc_ctx *ctx, const double *X, const double *t,
+                   double alpha);
+
+/* ---- unit entry points (the reference's inline "callbacks") -------------- */
+
+/* C1  log-joint  LJL(w) = f't - sum log(1+e^f) + log N(w;0,alpha I)
+ *     rmhmc.py:31-34,166-169 ; tools.py:10-14.   w[n*D] -> ljl_out[n]        */
+int rmhmc_log_posterior(rmhmc_ctx *ctx, const double *w, double *ljl_out);
+
+/* C2+C3  gradient and metric at w.   rmhmc.py:51-60, 99-100, 134-140.
+ *     G_out[n*D*D] (full symmetric) | NULL,
+ *     half_logdet_out[n] = sum log diag chol(G) (rmhmc.py:171,175) | NULL,
+ *     grad_out[n*D] | NULL.                                                  */
+int rmhmc_metric(rmhmc_ctx *ctx, const double *w, double *G_out,
+                 double *half_logdet_out, double *grad_out);
+
+/* C4  the two contractions of the metric-derivative tensor that the sampler
+ *     uses (rmhmc.py:64-77,104-107,142-161):
+ *       trace_out[n*D]  = tr(G^-1 dG/dw_d)
+ *       quad_out[n*D]   = u' (dG/dw_d) u  with u = G^-1 p      (NULL if p NULL)
+ *     so that LastTerm_d = 0.5*quad_d.                                        */
+int rmhmc_metric_terms(rmhmc_ctx *ctx, const double *w, const double *p,
+                       double *trace_out, double *quad_out);
+
+/* a3-a6  nsteps[c] generalised leapfrog steps of size eps in direction
+ *     dir[c] (+1/-1) with K fixed-point iterations (rmhmc.py:96-163).
+ *     w, p: in/out [n*D].  half_logdet_out[n] | NULL: at the final point.
+ *     status_out[n] | NULL.                                                  */
+int rmhmc_leapfrog(rmhmc_ctx *ctx, double *w, double *p, double eps,
+                   const int32_t *dir, const int32_t *nsteps, int32_t K,
+                   double *half_logdet_out, int32_t *status_out);
+
+/* a1-a7  one full MCMC transition with caller-supplied randomness, in the
+ *     reference's draw order (rmhmc.py:80,89,90,181):
+ *       z[n*D]   ~ randn(1,D)      momentum noise
+ *       u_len[n] ~ rand()          RandomStep = ceil(u_len*L)
+ *       g_dir[n] ~ randn()         TimeStep = +1 iff g_dir > 0.5
+ *       u_acc[n] ~ rand()          accept iff Ratio>0 or Ratio>log(u_acc)
+ *     w in/out.  All outputs optional (NULL).                                 */
+int rmhmc_transition(rmhmc_ctx *ctx, double *w, const double *z,
+                     const double *u_len, const double *g_dir,
+                     const double *u_acc, int32_t L, double eps, int32_t K,
+                     int32_t *accepted_out, int32_t *nsteps_out,
+                     double *H_cur_out, double *H_prop_out,
+                     double *w_prop_out, double *p_prop_out,
+                     double *half_logdet_prop_out, int32_t *status_out);
+
+/* ---- bulk entry points -------------------------------------------------- */
+
+/* a0-a8  RMHMC(XX, t, n_iter, burn_in, L, eps, K) for all chains.
+ *     Randomness: Philox4x32-10 keyed by seed, counter (chain_offset+chain,
+ *     iteration, draw) — identical streams whatever the sharding.
+ *     theta0[n*D] | NULL (NULL: 1e-3 everywhere, rmhmc.py:27).
+ *     samples_out[n*S*D], S = n_iter-burn_in; row s of chain c = state after
+ *     iteration burn_in+s (row 0 is left unwritten by rmhmc.py:190-191; here
+ *     it holds the state after iteration burn_in).
+ *     accept_out[n] | NULL : accepted proposals over all n_iter iterations.
+ *     steps_out[n]  | NULL : leapfrog steps executed after burn-in.
+ *     seconds_out   | NULL : wall seconds of the post-burn-in phase
+ *                            (TimeTaken, rmhmc.py:194-198).                  */
+int rmhmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L,
+                 double eps, int32_t K, uint64_t seed, int64_t chain_offset,
+                 const double *theta0, double *samples_out,
+                 int64_t *accept_out, int64_t *steps_out,
+                 double *seconds_out);
+
+/* Stateful form used by the benchmark and the multi-GPU driver: set the
+ * chain state once, then advance every chain by `n_steps` leapfrog steps
+ * (chains start a new transition whenever their trajectory ends, so every
+ * chain executes exactly n_steps leapfrog steps).  rmhmc_chains_run is
+ * synchronous: the device is idle when it returns.                          */
+int rmhmc_chains_init(rmhmc_ctx *ctx, const double *theta0, uint64_t seed,
+                      int64_t chain_offset, int32_t L, double eps, int32_t K);
+int rmhmc_chains_run(rmhmc_ctx *ctx, int64_t n_steps);
+/* Current position of every chain, completed transitions, accepted ones.    */
+int rmhmc_chains_state(rmhmc_ctx *ctx, double *w_out, int64_t *iters_out,
+                       int64_t *accept_out);
+/* Device seconds (HIP events on the library's stream) of the kernel named
+ * `which` accumulated since the last rmhmc_chains_init, and its launch
+ * count; which = "assemble" | "factor" | "momentum" | "leverage" | "total". */
+int rmhmc_kernel_time(rmhmc_ctx *ctx, const char *which, double *seconds_out,
+                      int64_t *launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMHMC_H */

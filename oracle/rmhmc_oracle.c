@@ -1,0 +1,844 @@
+/*
+ * rmhmc_oracle.c — CPU restatement of the RMHMC hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP library: a plain-C restatement of
+ * emilemathieu/RiemannHamiltonianMonteCarlo  code/rmhmc.py:13-201  exporting the
+ * C-ABI of include/rmhmc.h.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; the product path never does.
+ *
+ * Pinning: the oracle is checked in tests/test_oracle_golden.py against golden
+ * vectors captured from the reference itself (tests/golden/make_golden.py imports
+ * /root/reference/code/rmhmc.py under sys.settrace and records its locals).
+ *
+ * Two algorithm variants, selected by RMHMC_FLAG_ORACLE_LITERAL:
+ *   literal      forms the DxDxD tensor InvGdG[d] = G^-1 dG/dw_d and uses LU
+ *                inverse / LU solve exactly where rmhmc.py uses np.linalg.inv /
+ *                np.linalg.solve; recomputes the set-up block every transition.
+ *   matrix-free  never forms the tensor: tr(G^-1 dG_d) = sum_n c_n h_n x_nd with
+ *                h_n = x_n' G^-1 x_n, and u' dG_d u = sum_n c_n (x_n'u)^2 x_nd,
+ *                c = v(1-2p); Cholesky instead of LU; caches the point record
+ *                (G, chol, G^-1, grad, trace) instead of recomputing it.  This is
+ *                the algorithm the HIP kernels implement.
+ *
+ * Build:  make -C oracle      (gcc -O2 -fopenmp -shared -fPIC)
+ */
+#include "../include/rmhmc.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI2 6.283185307179586476925286766559
+
+struct rmhmc_ctx {
+  int64_t M;
+  int32_t D;
+  int64_t n;
+  uint32_t flags;
+  double alpha;
+  double *X; /* M*D row-major copy */
+  double *t; /* M */
+  int have_data;
+  char err[256];
+  /* stateful chain API */
+  int chains_ready;
+  uint64_t seed;
+  int64_t chain_offset;
+  int32_t L, K;
+  double eps;
+  struct chain *chains;
+};
+
+static char g_err[256] = "";
+
+static int fail(rmhmc_ctx *ctx, int code, const char *msg) {
+  snprintf(ctx ? ctx->err : g_err, 256, "%s", msg);
+  return code;
+}
+
+const char *rmhmc_version(void) { return "rmhmc-oracle-cpu 0.1 (C restatement of code/rmhmc.py)"; }
+const char *rmhmc_last_error(const rmhmc_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int rmhmc_device_info(rmhmc_ctx *ctx, char *buf, size_t len) {
+  int th = 1;
+#ifdef _OPENMP
+  th = omp_get_max_threads();
+#endif
+  (void)ctx;
+  snprintf(buf, len, "cpu oracle, %d OpenMP threads", th);
+  return RMHMC_OK;
+}
+
+int rmhmc_create(rmhmc_ctx **out, int32_t device_id, int64_t M, int32_t D, int64_t n_chains,
+                 int32_t dtype, uint32_t flags) {
+  (void)device_id;
+  if (!out || M <= 0 || D <= 0 || n_chains <= 0) return fail(NULL, RMHMC_ERR_INVALID, "bad shape");
+  if (dtype != RMHMC_F64) return fail(NULL, RMHMC_ERR_UNSUPPORTED, "only float64");
+  rmhmc_ctx *c = (rmhmc_ctx *)calloc(1, sizeof(*c));
+  if (!c) return fail(NULL, RMHMC_ERR_NOMEM, "oom");
+  c->M = M; c->D = D; c->n = n_chains; c->flags = flags; c->alpha = 100.0;
+  c->X = (double *)malloc(sizeof(double) * M * D);
+  c->t = (double *)malloc(sizeof(double) * M);
+  if (!c->X || !c->t) { free(c->X); free(c->t); free(c); return fail(NULL, RMHMC_ERR_NOMEM, "oom"); }
+  *out = c;
+  return RMHMC_OK;
+}
+
+int rmhmc_set_data(rmhmc_ctx *ctx, const double *X, const double *t, double alpha) {
+  if (!ctx || !X || !t || !(alpha > 0)) return fail(ctx, RMHMC_ERR_INVALID, "set_data: bad argument");
+  memcpy(ctx->X, X, sizeof(double) * ctx->M * ctx->D);
+  memcpy(ctx->t, t, sizeof(double) * ctx->M);
+  ctx->alpha = alpha;
+  ctx->have_data = 1;
+  ctx->chains_ready = 0;
+  return RMHMC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* small dense helpers                                                      */
+/* ------------------------------------------------------------------------ */
+
+/* lower Cholesky, A (D*D, full symmetric) -> L (lower, upper part zeroed).
+ * np.linalg.cholesky, rmhmc.py:60,171.  Returns 0 ok, 1 if a pivot is <=0/NaN
+ * (L is then filled with NaN so that every derived quantity is NaN => reject). */
+static int chol_lower(int D, const double *A, double *L) {
+  memset(L, 0, sizeof(double) * D * D);
+  for (int j = 0; j < D; j++) {
+    double s = A[j * D + j];
+    for (int k = 0; k < j; k++) s -= L[j * D + k] * L[j * D + k];
+    if (!(s > 0.0)) {
+      for (int i = 0; i < D * D; i++) L[i] = NAN;
+      return 1;
+    }
+    double ljj = sqrt(s);
+    L[j * D + j] = ljj;
+    for (int i = j + 1; i < D; i++) {
+      double a = A[i * D + j];
+      for (int k = 0; k < j; k++) a -= L[i * D + k] * L[j * D + k];
+      L[i * D + j] = a / ljj;
+    }
+  }
+  return 0;
+}
+
+/* x = (L L')^-1 b */
+static void chol_solve(int D, const double *L, const double *b, double *x) {
+  for (int i = 0; i < D; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= L[i * D + k] * x[k];
+    x[i] = s / L[i * D + i];
+  }
+  for (int i = D - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < D; k++) s -= L[k * D + i] * x[k];
+    x[i] = s / L[i * D + i];
+  }
+}
+
+/* Ginv = (L L')^-1, full symmetric */
+static void chol_inverse(int D, const double *L, double *Ginv, double *tmp /* D */) {
+  double *e = tmp;
+  for (int j = 0; j < D; j++) {
+    memset(e, 0, sizeof(double) * D);
+    e[j] = 1.0;
+    chol_solve(D, L, e, &Ginv[j * D]); /* column j == row j by symmetry */
+  }
+  for (int i = 0; i < D; i++)
+    for (int j = i + 1; j < D; j++) {
+      double m = 0.5 * (Ginv[i * D + j] + Ginv[j * D + i]);
+      Ginv[i * D + j] = Ginv[j * D + i] = m;
+    }
+}
+
+static double half_logdet(int D, const double *L) {
+  double s = 0;
+  for (int i = 0; i < D; i++) s += log(L[i * D + i]);
+  return s;
+}
+
+/* LU with partial pivoting (dgetrf-style), in place; piv[D]. returns 1 if singular */
+static int lu_factor(int D, double *A, int *piv) {
+  int sing = 0;
+  for (int k = 0; k < D; k++) {
+    int p = k;
+    double best = fabs(A[k * D + k]);
+    for (int i = k + 1; i < D; i++)
+      if (fabs(A[i * D + k]) > best) { best = fabs(A[i * D + k]); p = i; }
+    piv[k] = p;
+    if (p != k)
+      for (int j = 0; j < D; j++) { double tmp = A[k * D + j]; A[k * D + j] = A[p * D + j]; A[p * D + j] = tmp; }
+    double d = A[k * D + k];
+    if (d == 0.0 || d != d) { sing = 1; continue; }
+    for (int i = k + 1; i < D; i++) {
+      double m = A[i * D + k] / d;
+      A[i * D + k] = m;
+      for (int j = k + 1; j < D; j++) A[i * D + j] -= m * A[k * D + j];
+    }
+  }
+  return sing;
+}
+static void lu_solve(int D, const double *LU, const int *piv, double *b) {
+  for (int k = 0; k < D; k++) { int p = piv[k]; if (p != k) { double tmp = b[k]; b[k] = b[p]; b[p] = tmp; } }
+  for (int i = 0; i < D; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= LU[i * D + k] * b[k]; b[i] = s; }
+  for (int i = D - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < D; k++) s -= LU[i * D + k] * b[k]; b[i] = s / LU[i * D + i]; }
+}
+/* np.linalg.solve(G, b)  (rmhmc.py:113,121): dgesv */
+static void lu_solve_copy(int D, const double *G, const double *b, double *x, double *work /* D*D */, int *piv) {
+  memcpy(work, G, sizeof(double) * D * D);
+  lu_factor(D, work, piv);
+  memcpy(x, b, sizeof(double) * D);
+  lu_solve(D, work, piv, x);
+}
+/* np.linalg.inv(G) (rmhmc.py:58,138): dgesv against the identity */
+static void lu_inverse(int D, const double *G, double *Ginv, double *work /* D*D */, int *piv, double *col /* D */) {
+  memcpy(work, G, sizeof(double) * D * D);
+  lu_factor(D, work, piv);
+  for (int j = 0; j < D; j++) {
+    memset(col, 0, sizeof(double) * D);
+    col[j] = 1.0;
+    lu_solve(D, work, piv, col);
+    for (int i = 0; i < D; i++) Ginv[i * D + j] = col[i];
+  }
+}
+
+static double norm2(int D, const double *x) {
+  double s = 0;
+  for (int i = 0; i < D; i++) s += x[i] * x[i];
+  return sqrt(s);
+}
+static void matvec(int D, const double *A, const double *x, double *y) {
+  for (int i = 0; i < D; i++) {
+    double s = 0;
+    for (int j = 0; j < D; j++) s += A[i * D + j] * x[j];
+    y[i] = s;
+  }
+}
+static double dot(int D, const double *a, const double *b) {
+  double s = 0;
+  for (int i = 0; i < D; i++) s += a[i] * b[i];
+  return s;
+}
+
+/* ------------------------------------------------------------------------ */
+/* the reference's inline "callbacks"                                       */
+/* ------------------------------------------------------------------------ */
+
+/* C1: log-joint.  rmhmc.py:31-34,166-169; tools.LogNormPDF tools.py:10-14.
+ * Naive log(1+exp(f)) on purpose: overflows to +inf for f>709 like the reference. */
+static double log_joint(const rmhmc_ctx *c, const double *w) {
+  const int D = c->D;
+  double ll = 0;
+  for (int64_t n = 0; n < c->M; n++) {
+    double f = dot(D, &c->X[n * D], w);
+    ll += f * c->t[n] - log(1.0 + exp(f));
+  }
+  double lp = 0;
+  for (int d = 0; d < D; d++) lp += -0.5 * log(PI2 * c->alpha) - w[d] * w[d] / (2.0 * c->alpha);
+  return ll + lp;
+}
+
+/* C2: gradient  X'(t - e^f/(1+e^f)) - w/alpha.  rmhmc.py:99-100,140
+ * (the e^f/(1+e^f) form: NaN for f>709, like the reference). */
+static void gradient(const rmhmc_ctx *c, const double *w, double *g) {
+  const int D = c->D;
+  for (int d = 0; d < D; d++) g[d] = 0;
+  for (int64_t n = 0; n < c->M; n++) {
+    const double *x = &c->X[n * D];
+    double f = dot(D, x, w), e = exp(f);
+    double r = c->t[n] - e / (1.0 + e);
+    for (int d = 0; d < D; d++) g[d] += r * x[d];
+  }
+  for (int d = 0; d < D; d++) g[d] -= w[d] / c->alpha;
+}
+
+/* C3: metric  G = X' diag(v) X + I/alpha, v = p(1-p), p = 1/(1+e^-f).
+ * rmhmc.py:51-57,116-119,134-137.  Optionally returns c_n = v_n(1-2p_n). */
+static void metric(const rmhmc_ctx *c, const double *w, double *G, double *cvec) {
+  const int D = c->D;
+  memset(G, 0, sizeof(double) * D * D);
+  for (int64_t n = 0; n < c->M; n++) {
+    const double *x = &c->X[n * D];
+    double f = dot(D, x, w);
+    double p = 1.0 / (1.0 + exp(-f));
+    double v = p * (1.0 - p);
+    if (cvec) cvec[n] = v * (1.0 - 2.0 * p);
+    for (int a = 0; a < D; a++) {
+      double va = v * x[a];
+      for (int b = a; b < D; b++) G[a * D + b] += va * x[b];
+    }
+  }
+  for (int a = 0; a < D; a++) {
+    G[a * D + a] += 1.0 / c->alpha;
+    for (int b = a + 1; b < D; b++) G[b * D + a] = G[a * D + b];
+  }
+}
+
+/* C4 matrix-free: tr_d = sum_n c_n h_n x_nd, h_n = x_n' Ginv x_n  (== np.trace(InvG.dot(GDeriv)),
+ * rmhmc.py:67-77) */
+static void trace_term_mf(const rmhmc_ctx *c, const double *cvec, const double *Ginv, double *tr, double *tmp /* D */) {
+  const int D = c->D;
+  for (int d = 0; d < D; d++) tr[d] = 0;
+  for (int64_t n = 0; n < c->M; n++) {
+    const double *x = &c->X[n * D];
+    matvec(D, Ginv, x, tmp);
+    double h = dot(D, x, tmp) * cvec[n];
+    for (int d = 0; d < D; d++) tr[d] += h * x[d];
+  }
+}
+/* C4 matrix-free: quad_d = u' dG_d u = sum_n c_n (x_n'u)^2 x_nd  (LastTerm = quad/2, rmhmc.py:104-107) */
+static void quad_term_mf(const rmhmc_ctx *c, const double *cvec, const double *u, double *q) {
+  const int D = c->D;
+  for (int d = 0; d < D; d++) q[d] = 0;
+  for (int64_t n = 0; n < c->M; n++) {
+    const double *x = &c->X[n * D];
+    double s = dot(D, x, u);
+    double r = cvec[n] * s * s;
+    for (int d = 0; d < D; d++) q[d] += r * x[d];
+  }
+}
+
+/* C4 literal: InvGdG[d] = InvG . (X' diag(v(1-2p)x_d) X), Trace[d].  rmhmc.py:64-77,142-156 */
+static void tensor_literal(const rmhmc_ctx *c, const double *w, const double *InvG, double *T /* D^3 */, double *tr, double *GD /* D*D */) {
+  const int D = c->D;
+  double *cv = (double *)malloc(sizeof(double) * c->M);
+  for (int64_t n = 0; n < c->M; n++) {
+    double f = dot(D, &c->X[n * D], w);
+    double p = 1.0 / (1.0 + exp(-f));
+    cv[n] = p * (1.0 - p) * (1.0 - 2.0 * p);
+  }
+  for (int d = 0; d < D; d++) {
+    memset(GD, 0, sizeof(double) * D * D);
+    for (int64_t n = 0; n < c->M; n++) {
+      const double *x = &c->X[n * D];
+      double z1 = cv[n] * x[d];
+      for (int a = 0; a < D; a++) {
+        double za = z1 * x[a];
+        for (int b = 0; b < D; b++) GD[a * D + b] += za * x[b];
+      }
+    }
+    double *Td = &T[(size_t)d * D * D];
+    double trd = 0;
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) {
+        double s = 0;
+        for (int k = 0; k < D; k++) s += InvG[i * D + k] * GD[k * D + j];
+        Td[i * D + j] = s;
+        if (i == j) trd += s;
+      }
+    tr[d] = trd;
+  }
+  free(cv);
+}
+
+/* ------------------------------------------------------------------------ */
+/* point record + workspace                                                 */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  double *w, *grad, *tr, *G, *L, *Ginv, *cvec; /* D, D, D, D*D, D*D, D*D, M */
+  double *T;                                   /* D^3, literal only */
+  double ljl, hld;
+  int status;
+} point_t;
+
+typedef struct {
+  double *G2, *L2, *tmpDD, *a, *b, *u, *u0, *PM, *Pw, *q, *tmpD;
+  int *piv;
+} work_t;
+
+static void point_alloc(const rmhmc_ctx *c, point_t *pt, int literal) {
+  const int D = c->D;
+  pt->w = (double *)calloc(D, sizeof(double));
+  pt->grad = (double *)calloc(D, sizeof(double));
+  pt->tr = (double *)calloc(D, sizeof(double));
+  pt->G = (double *)calloc((size_t)D * D, sizeof(double));
+  pt->L = (double *)calloc((size_t)D * D, sizeof(double));
+  pt->Ginv = (double *)calloc((size_t)D * D, sizeof(double));
+  pt->cvec = (double *)calloc(c->M, sizeof(double));
+  pt->T = literal ? (double *)calloc((size_t)D * D * D, sizeof(double)) : NULL;
+  pt->ljl = pt->hld = 0;
+  pt->status = 0;
+}
+static void point_free(point_t *pt) {
+  free(pt->w); free(pt->grad); free(pt->tr); free(pt->G); free(pt->L); free(pt->Ginv); free(pt->cvec); free(pt->T);
+}
+static void point_copy(const rmhmc_ctx *c, point_t *dst, const point_t *src) {
+  const int D = c->D;
+  memcpy(dst->w, src->w, sizeof(double) * D);
+  memcpy(dst->grad, src->grad, sizeof(double) * D);
+  memcpy(dst->tr, src->tr, sizeof(double) * D);
+  memcpy(dst->G, src->G, sizeof(double) * D * D);
+  memcpy(dst->L, src->L, sizeof(double) * D * D);
+  memcpy(dst->Ginv, src->Ginv, sizeof(double) * D * D);
+  memcpy(dst->cvec, src->cvec, sizeof(double) * c->M);
+  if (dst->T && src->T) memcpy(dst->T, src->T, sizeof(double) * D * D * D);
+  dst->ljl = src->ljl; dst->hld = src->hld; dst->status = src->status;
+}
+static void work_alloc(const rmhmc_ctx *c, work_t *k) {
+  const int D = c->D;
+  k->G2 = (double *)calloc((size_t)D * D, sizeof(double));
+  k->L2 = (double *)calloc((size_t)D * D, sizeof(double));
+  k->tmpDD = (double *)calloc((size_t)D * D, sizeof(double));
+  k->a = (double *)calloc(D, sizeof(double)); k->b = (double *)calloc(D, sizeof(double));
+  k->u = (double *)calloc(D, sizeof(double)); k->u0 = (double *)calloc(D, sizeof(double));
+  k->PM = (double *)calloc(D, sizeof(double)); k->Pw = (double *)calloc(D, sizeof(double));
+  k->q = (double *)calloc(D, sizeof(double)); k->tmpD = (double *)calloc(D, sizeof(double));
+  k->piv = (int *)calloc(D, sizeof(int));
+}
+static void work_free(work_t *k) {
+  free(k->G2); free(k->L2); free(k->tmpDD); free(k->a); free(k->b); free(k->u); free(k->u0);
+  free(k->PM); free(k->Pw); free(k->q); free(k->tmpD); free(k->piv);
+}
+
+/* Evaluate everything the sampler needs at pt->w.
+ * matrix-free: G, chol, hld, Ginv (from chol), grad, ljl, cvec, trace term.
+ * literal: G, LU inverse, chol (for hld / momentum draw), grad, ljl, tensor + trace. */
+static void point_eval(const rmhmc_ctx *c, point_t *pt, work_t *k, int literal) {
+  const int D = c->D;
+  metric(c, pt->w, pt->G, pt->cvec);
+  pt->status = chol_lower(D, pt->G, pt->L) ? RMHMC_ST_NOT_PD : 0;
+  pt->hld = half_logdet(D, pt->L);
+  gradient(c, pt->w, pt->grad);
+  pt->ljl = log_joint(c, pt->w);
+  if (literal) {
+    lu_inverse(D, pt->G, pt->Ginv, k->tmpDD, k->piv, k->tmpD);
+    tensor_literal(c, pt->w, pt->Ginv, pt->T, pt->tr, k->G2);
+  } else {
+    chol_inverse(D, pt->L, pt->Ginv, k->tmpD);
+    trace_term_mf(c, pt->cvec, pt->Ginv, pt->tr, k->tmpD);
+  }
+}
+
+/* LastTerm_d = 0.5 * PM' InvGdG[d] InvG PM   (rmhmc.py:104-107,158-161) */
+static void last_term(const rmhmc_ctx *c, const point_t *pt, const double *PM, double *last, work_t *k, int literal) {
+  const int D = c->D;
+  matvec(D, pt->Ginv, PM, k->u);
+  if (literal) {
+    for (int d = 0; d < D; d++) {
+      const double *Td = &pt->T[(size_t)d * D * D];
+      /* PM' Td u */
+      double s = 0;
+      for (int i = 0; i < D; i++) {
+        double r = 0;
+        for (int j = 0; j < D; j++) r += Td[i * D + j] * k->u[j];
+        s += PM[i] * r;
+      }
+      last[d] = 0.5 * s;
+    }
+  } else {
+    quad_term_mf(c, pt->cvec, k->u, last);
+    for (int d = 0; d < D; d++) last[d] *= 0.5;
+  }
+}
+
+/* One generalised leapfrog step (rmhmc.py:96-163).  pt: record at the current
+ * w (in/out: replaced by the record at the new w); p in/out. */
+static void leapfrog_step(const rmhmc_ctx *c, point_t *pt, double *p, double tau, double eps, int K, work_t *k, int literal, int *status) {
+  const int D = c->D;
+  const double h = tau * eps / 2.0;
+  /* implicit momentum half step, K fixed-point iterations, rmhmc.py:102-110 */
+  memcpy(k->PM, p, sizeof(double) * D);
+  for (int it = 0; it < K; it++) {
+    last_term(c, pt, k->PM, k->q, k, literal);
+    for (int d = 0; d < D; d++) k->PM[d] = p[d] + h * (pt->grad[d] - 0.5 * pt->tr[d] + k->q[d]);
+  }
+  memcpy(p, k->PM, sizeof(double) * D);
+  /* implicit position step, rmhmc.py:113-123 */
+  if (literal) lu_solve_copy(D, pt->G, p, k->u0, k->tmpDD, k->piv);
+  else chol_solve(D, pt->L, p, k->u0);
+  memcpy(k->Pw, pt->w, sizeof(double) * D);
+  for (int it = 0; it < K; it++) {
+    if (literal) {
+      metric(c, k->Pw, k->G2, NULL); /* rmhmc.py:116-119 (recomputed even for it==0) */
+      lu_solve_copy(D, k->G2, p, k->u, k->tmpDD, k->piv);
+    } else if (it == 0) {
+      memcpy(k->u, k->u0, sizeof(double) * D); /* G(Pw^0) == G(w): same expression, same input */
+    } else {
+      metric(c, k->Pw, k->G2, NULL);
+      if (chol_lower(D, k->G2, k->L2)) *status |= RMHMC_ST_NOT_PD;
+      chol_solve(D, k->L2, p, k->u);
+    }
+    for (int d = 0; d < D; d++) k->Pw[d] = pt->w[d] + h * (k->u0[d] + k->u[d]);
+  }
+  memcpy(pt->w, k->Pw, sizeof(double) * D);
+  /* position guard, rmhmc.py:125-130 */
+  if (c->flags & RMHMC_FLAG_GUARDS) {
+    double nw = norm2(D, pt->w);
+    if (nw > 10.0) {
+      for (int d = 0; d < D; d++) pt->w[d] /= nw * 3.0;
+      *status |= RMHMC_ST_GUARD_W;
+    }
+  }
+  /* explicit momentum half step at the new w, rmhmc.py:134-163 */
+  point_eval(c, pt, k, literal);
+  *status |= pt->status;
+  last_term(c, pt, p, k->q, k, literal);
+  for (int d = 0; d < D; d++) p[d] += h * (pt->grad[d] - 0.5 * pt->tr[d] + k->q[d]);
+  for (int d = 0; d < D; d++)
+    if (!isfinite(pt->w[d]) || !isfinite(p[d])) *status |= RMHMC_ST_NONFINITE;
+}
+
+/* momentum draw + guard, rmhmc.py:80-87 */
+static void draw_momentum(const rmhmc_ctx *c, const double *L, const double *z, double *p, int *status) {
+  const int D = c->D;
+  if (c->flags & RMHMC_FLAG_MOMENTUM_LT) { /* (z L)' = L' z */
+    for (int j = 0; j < D; j++) { double s = 0; for (int i = j; i < D; i++) s += L[i * D + j] * z[i]; p[j] = s; }
+  } else { /* L z : Cov = G, as BLR_RMHMC.m:231,249 with upper chol */
+    for (int i = 0; i < D; i++) { double s = 0; for (int j = 0; j <= i; j++) s += L[i * D + j] * z[j]; p[i] = s; }
+  }
+  if (c->flags & RMHMC_FLAG_GUARDS) {
+    double np_ = norm2(D, p);
+    if (np_ > 100.0) { for (int d = 0; d < D; d++) p[d] /= np_ * 25.0; *status |= RMHMC_ST_GUARD_P; }
+  }
+}
+
+/* H = -LJL + 0.5 log|G| + 0.5 p' G^-1 p   (rmhmc.py:171-172,175-176) */
+static double hamiltonian(const rmhmc_ctx *c, const point_t *pt, const double *p, work_t *k) {
+  matvec(c->D, pt->Ginv, p, k->tmpD);
+  return -pt->ljl + pt->hld + 0.5 * dot(c->D, p, k->tmpD);
+}
+
+typedef struct {
+  int accepted, nsteps, dir, status;
+  double H_cur, H_prop, hld_prop;
+} trans_out_t;
+
+/* One transition (rmhmc.py:47-184) from the cached record `cur`; `trj` is scratch.
+ * Literal mode re-evaluates the set-up block like the reference does (:50-77). */
+static void transition(const rmhmc_ctx *c, point_t *cur, point_t *trj, double *p, const double *z, double u_len,
+                       double g_dir, double u_acc, int L, double eps, int K, work_t *k, int literal, trans_out_t *o,
+                       double *p0 /* D scratch */) {
+  const int D = c->D;
+  int status = 0;
+  if (literal) point_eval(c, cur, k, 1);
+  point_copy(c, trj, cur);
+  draw_momentum(c, cur->L, z, p, &status);
+  memcpy(p0, p, sizeof(double) * D);
+  int nsteps = (int)ceil(u_len * L);       /* rmhmc.py:89 */
+  double tau = (g_dir > 0.5) ? 1.0 : -1.0; /* rmhmc.py:90-93 */
+  for (int s = 0; s < nsteps; s++) leapfrog_step(c, trj, p, tau, eps, K, k, literal, &status);
+  double Hp = hamiltonian(c, trj, p, k);
+  double Hc = hamiltonian(c, cur, p0, k);
+  if (literal) { /* rmhmc.py:175 uses the stored CurrentLJL; identical value */ }
+  double ratio = -Hp + Hc;
+  int acc = (ratio > 0) || (ratio > log(u_acc)); /* rmhmc.py:181 */
+  o->accepted = acc; o->nsteps = nsteps; o->dir = (int)tau; o->status = status;
+  o->H_cur = Hc; o->H_prop = Hp; o->hld_prop = trj->hld;
+}
+
+/* ------------------------------------------------------------------------ */
+/* unit entry points                                                        */
+/* ------------------------------------------------------------------------ */
+#define NEED_DATA(ctx) if (!(ctx) || !(ctx)->have_data) return fail(ctx, RMHMC_ERR_INVALID, "set_data not called")
+#define LITERAL(ctx) (((ctx)->flags & RMHMC_FLAG_ORACLE_LITERAL) != 0)
+
+int rmhmc_log_posterior(rmhmc_ctx *ctx, const double *w, double *ljl_out) {
+  NEED_DATA(ctx);
+  const int D = ctx->D;
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) ljl_out[c] = log_joint(ctx, &w[c * D]);
+  return RMHMC_OK;
+}
+
+int rmhmc_metric(rmhmc_ctx *ctx, const double *w, double *G_out, double *half_logdet_out, double *grad_out) {
+  NEED_DATA(ctx);
+  const int D = ctx->D;
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    double *G = (double *)malloc(sizeof(double) * D * D), *L = (double *)malloc(sizeof(double) * D * D);
+    metric(ctx, &w[c * D], G, NULL);
+    if (G_out) memcpy(&G_out[c * D * D], G, sizeof(double) * D * D);
+    if (half_logdet_out) { chol_lower(D, G, L); half_logdet_out[c] = half_logdet(D, L); }
+    if (grad_out) gradient(ctx, &w[c * D], &grad_out[c * D]);
+    free(G); free(L);
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_metric_terms(rmhmc_ctx *ctx, const double *w, const double *p, double *trace_out, double *quad_out) {
+  NEED_DATA(ctx);
+  const int D = ctx->D;
+  const int lit = LITERAL(ctx);
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    point_t pt; work_t k;
+    point_alloc(ctx, &pt, lit); work_alloc(ctx, &k);
+    memcpy(pt.w, &w[c * D], sizeof(double) * D);
+    point_eval(ctx, &pt, &k, lit);
+    if (trace_out) memcpy(&trace_out[c * D], pt.tr, sizeof(double) * D);
+    if (p && quad_out) {
+      last_term(ctx, &pt, &p[c * D], k.q, &k, lit);
+      for (int d = 0; d < D; d++) quad_out[c * D + d] = 2.0 * k.q[d];
+    }
+    point_free(&pt); work_free(&k);
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_leapfrog(rmhmc_ctx *ctx, double *w, double *p, double eps, const int32_t *dir, const int32_t *nsteps,
+                   int32_t K, double *half_logdet_out, int32_t *status_out) {
+  NEED_DATA(ctx);
+  const int D = ctx->D;
+  const int lit = LITERAL(ctx);
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    point_t pt; work_t k;
+    point_alloc(ctx, &pt, lit); work_alloc(ctx, &k);
+    memcpy(pt.w, &w[c * D], sizeof(double) * D);
+    point_eval(ctx, &pt, &k, lit);
+    int st = pt.status;
+    for (int s = 0; s < nsteps[c]; s++) leapfrog_step(ctx, &pt, &p[c * D], (double)dir[c], eps, K, &k, lit, &st);
+    memcpy(&w[c * D], pt.w, sizeof(double) * D);
+    if (half_logdet_out) half_logdet_out[c] = pt.hld;
+    if (status_out) status_out[c] = st;
+    point_free(&pt); work_free(&k);
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_transition(rmhmc_ctx *ctx, double *w, const double *z, const double *u_len, const double *g_dir,
+                     const double *u_acc, int32_t L, double eps, int32_t K, int32_t *accepted_out,
+                     int32_t *nsteps_out, double *H_cur_out, double *H_prop_out, double *w_prop_out,
+                     double *p_prop_out, double *half_logdet_prop_out, int32_t *status_out) {
+  NEED_DATA(ctx);
+  const int D = ctx->D;
+  const int lit = LITERAL(ctx);
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    point_t cur, trj; work_t k; trans_out_t o;
+    point_alloc(ctx, &cur, lit); point_alloc(ctx, &trj, lit); work_alloc(ctx, &k);
+    double *p = (double *)calloc(D, sizeof(double)), *p0 = (double *)calloc(D, sizeof(double));
+    memcpy(cur.w, &w[c * D], sizeof(double) * D);
+    if (!lit) point_eval(ctx, &cur, &k, 0);
+    transition(ctx, &cur, &trj, p, &z[c * D], u_len[c], g_dir[c], u_acc[c], L, eps, K, &k, lit, &o, p0);
+    if (o.accepted) memcpy(&w[c * D], trj.w, sizeof(double) * D);
+    if (accepted_out) accepted_out[c] = o.accepted;
+    if (nsteps_out) nsteps_out[c] = o.nsteps;
+    if (H_cur_out) H_cur_out[c] = o.H_cur;
+    if (H_prop_out) H_prop_out[c] = o.H_prop;
+    if (w_prop_out) memcpy(&w_prop_out[c * D], trj.w, sizeof(double) * D);
+    if (p_prop_out) memcpy(&p_prop_out[c * D], p, sizeof(double) * D);
+    if (half_logdet_prop_out) half_logdet_prop_out[c] = o.hld_prop;
+    if (status_out) status_out[c] = o.status;
+    free(p); free(p0);
+    point_free(&cur); point_free(&trj); work_free(&k);
+  }
+  return RMHMC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* counter-based RNG shared (by specification) with the HIP library          */
+/* ------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11).  key = seed, counter =
+ * (chain lo, chain hi, iteration, block).  Blocks 0..ceil(D/2)-1 give the D
+ * momentum normals by Box-Muller (2 per block); block 0x40000000 gives
+ * (u_len, u_acc); block 0x40000001 gives g_dir. */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+static double u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+}
+static void rng_block(uint64_t seed, uint64_t chain, uint32_t iter, uint32_t block, double *U0, double *U1) {
+  uint32_t c[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), iter, block};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  *U0 = u53(c[0], c[1]);
+  *U1 = u53(c[2], c[3]);
+}
+static void rng_draws(uint64_t seed, uint64_t chain, uint32_t iter, int D, double *z, double *u_len, double *g_dir, double *u_acc) {
+  for (int j = 0; 2 * j < D; j++) {
+    double U0, U1;
+    rng_block(seed, chain, iter, (uint32_t)j, &U0, &U1);
+    double R = sqrt(-2.0 * log(U0));
+    z[2 * j] = R * cos(PI2 * U1);
+    if (2 * j + 1 < D) z[2 * j + 1] = R * sin(PI2 * U1);
+  }
+  double U0, U1;
+  rng_block(seed, chain, iter, 0x40000000u, u_len, u_acc);
+  rng_block(seed, chain, iter, 0x40000001u, &U0, &U1);
+  *g_dir = sqrt(-2.0 * log(U0)) * cos(PI2 * U1);
+}
+/* exported for tests: raw Philox block (known-answer tests) and the draw recipe */
+void rmhmc_oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+  philox4x32_10(c, key[0], key[1]);
+  memcpy(out, c, sizeof(c));
+}
+void rmhmc_oracle_draws(uint64_t seed, uint64_t chain, uint32_t iter, int32_t D, double *z, double *u3 /* len,dir,acc */) {
+  rng_draws(seed, chain, iter, D, z, &u3[0], &u3[1], &u3[2]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* bulk entry points                                                        */
+/* ------------------------------------------------------------------------ */
+struct chain {
+  point_t cur, trj;
+  work_t k;
+  double *p, *p0, *z;
+  double H_cur, tau;
+  int steps_left;
+  int64_t iter, accepted, steps_done;
+  int status;
+};
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+int rmhmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                 int64_t chain_offset, const double *theta0, double *samples_out, int64_t *accept_out,
+                 int64_t *steps_out, double *seconds_out) {
+  NEED_DATA(ctx);
+  if (burn_in >= n_iter || burn_in < 0 || L < 1 || K < 0) return fail(ctx, RMHMC_ERR_INVALID, "need 0 <= burn_in < n_iter, L>=1");
+  const int D = ctx->D;
+  const int lit = LITERAL(ctx);
+  const int64_t S = n_iter - burn_in;
+  double t_post = 0;
+  int64_t *acc_all = (int64_t *)calloc(ctx->n, sizeof(int64_t));
+  /* Two phases so that the timer covers exactly the post-burn-in transitions of every chain
+   * (TimeTaken, rmhmc.py:194-198).  Between the phases a chain is represented by its position only
+   * (row 0 of its samples); its point record is re-evaluated, which is deterministic. */
+  for (int phase = 0; phase < 2; phase++) {
+    double t0 = now_s();
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t c = 0; c < ctx->n; c++) {
+      point_t cur, trj;
+      work_t k;
+      point_alloc(ctx, &cur, lit); point_alloc(ctx, &trj, lit); work_alloc(ctx, &k);
+      double *p = (double *)calloc(D, sizeof(double)), *p0 = (double *)calloc(D, sizeof(double)), *z = (double *)calloc(D + 1, sizeof(double));
+      int64_t it0, it1, steps = 0;
+      if (phase == 0) {
+        for (int d = 0; d < D; d++) cur.w[d] = theta0 ? theta0[c * D + d] : 1e-3; /* rmhmc.py:27 */
+        it0 = 0; it1 = burn_in + 1;
+      } else {
+        memcpy(cur.w, &samples_out[(c * S + 0) * D], sizeof(double) * D);
+        it0 = burn_in + 1; it1 = n_iter;
+      }
+      if (!lit) point_eval(ctx, &cur, &k, 0);
+      for (int64_t it = it0; it < it1; it++) {
+        double u_len, g_dir, u_acc;
+        trans_out_t o;
+        rng_draws(seed, (uint64_t)(chain_offset + c), (uint32_t)it, D, z, &u_len, &g_dir, &u_acc);
+        transition(ctx, &cur, &trj, p, z, u_len, g_dir, u_acc, L, eps, K, &k, lit, &o, p0);
+        if (o.accepted) { point_copy(ctx, &cur, &trj); acc_all[c]++; }
+        if (it >= burn_in) memcpy(&samples_out[(c * S + (it - burn_in)) * D], cur.w, sizeof(double) * D);
+        if (it > burn_in) steps += o.nsteps;
+      }
+      if (steps_out && phase == 1) steps_out[c] = steps;
+      free(p); free(p0); free(z);
+      point_free(&cur); point_free(&trj); work_free(&k);
+    }
+    if (phase == 1) t_post = now_s() - t0;
+  }
+  if (accept_out) memcpy(accept_out, acc_all, sizeof(int64_t) * ctx->n);
+  free(acc_all);
+  if (steps_out && n_iter == burn_in + 1)
+    for (int64_t c = 0; c < ctx->n; c++) steps_out[c] = 0;
+  if (seconds_out) *seconds_out = t_post;
+  return RMHMC_OK;
+}
+
+static void chain_begin(rmhmc_ctx *ctx, struct chain *ch, int64_t gid) {
+  double u_len, g_dir, u_acc;
+  rng_draws(ctx->seed, (uint64_t)gid, (uint32_t)ch->iter, ctx->D, ch->z, &u_len, &g_dir, &u_acc);
+  point_copy(ctx, &ch->trj, &ch->cur);
+  ch->status = 0;
+  draw_momentum(ctx, ch->cur.L, ch->z, ch->p, &ch->status);
+  memcpy(ch->p0, ch->p, sizeof(double) * ctx->D);
+  ch->steps_left = (int)ceil(u_len * ctx->L);
+  ch->tau = (g_dir > 0.5) ? 1.0 : -1.0;
+  ch->H_cur = hamiltonian(ctx, &ch->cur, ch->p0, &ch->k);
+}
+static void chain_end(rmhmc_ctx *ctx, struct chain *ch, int64_t gid) {
+  double u_len, g_dir, u_acc;
+  rng_draws(ctx->seed, (uint64_t)gid, (uint32_t)ch->iter, ctx->D, ch->z, &u_len, &g_dir, &u_acc);
+  double Hp = hamiltonian(ctx, &ch->trj, ch->p, &ch->k);
+  double ratio = -Hp + ch->H_cur;
+  if ((ratio > 0) || (ratio > log(u_acc))) { point_copy(ctx, &ch->cur, &ch->trj); ch->accepted++; }
+  ch->iter++;
+}
+
+int rmhmc_chains_init(rmhmc_ctx *ctx, const double *theta0, uint64_t seed, int64_t chain_offset, int32_t L, double eps, int32_t K) {
+  NEED_DATA(ctx);
+  if (LITERAL(ctx)) return fail(ctx, RMHMC_ERR_UNSUPPORTED, "chains_* API is matrix-free only");
+  const int D = ctx->D;
+  if (!ctx->chains) {
+    ctx->chains = (struct chain *)calloc(ctx->n, sizeof(struct chain));
+    for (int64_t c = 0; c < ctx->n; c++) {
+      struct chain *ch = &ctx->chains[c];
+      point_alloc(ctx, &ch->cur, 0); point_alloc(ctx, &ch->trj, 0); work_alloc(ctx, &ch->k);
+      ch->p = (double *)calloc(D, sizeof(double)); ch->p0 = (double *)calloc(D, sizeof(double)); ch->z = (double *)calloc(D + 1, sizeof(double));
+    }
+  }
+  ctx->seed = seed; ctx->chain_offset = chain_offset; ctx->L = L; ctx->eps = eps; ctx->K = K;
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    struct chain *ch = &ctx->chains[c];
+    for (int d = 0; d < D; d++) ch->cur.w[d] = theta0 ? theta0[c * D + d] : 1e-3;
+    point_eval(ctx, &ch->cur, &ch->k, 0);
+    ch->iter = 0; ch->accepted = 0; ch->steps_done = 0; ch->steps_left = 0;
+  }
+  ctx->chains_ready = 1;
+  return RMHMC_OK;
+}
+
+int rmhmc_chains_run(rmhmc_ctx *ctx, int64_t n_steps) {
+  if (!ctx || !ctx->chains_ready) return fail(ctx, RMHMC_ERR_INVALID, "chains_init not called");
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    struct chain *ch = &ctx->chains[c];
+    const int64_t gid = ctx->chain_offset + c;
+    for (int64_t s = 0; s < n_steps; s++) {
+      if (ch->steps_left == 0) chain_begin(ctx, ch, gid);
+      leapfrog_step(ctx, &ch->trj, ch->p, ch->tau, ctx->eps, ctx->K, &ch->k, 0, &ch->status);
+      ch->steps_done++;
+      if (--ch->steps_left == 0) chain_end(ctx, ch, gid);
+    }
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_chains_state(rmhmc_ctx *ctx, double *w_out, int64_t *iters_out, int64_t *accept_out) {
+  if (!ctx || !ctx->chains_ready) return fail(ctx, RMHMC_ERR_INVALID, "chains_init not called");
+  for (int64_t c = 0; c < ctx->n; c++) {
+    if (w_out) memcpy(&w_out[c * ctx->D], ctx->chains[c].cur.w, sizeof(double) * ctx->D);
+    if (iters_out) iters_out[c] = ctx->chains[c].iter;
+    if (accept_out) accept_out[c] = ctx->chains[c].accepted;
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_kernel_time(rmhmc_ctx *ctx, const char *which, double *seconds_out, int64_t *launches_out) {
+  (void)which;
+  if (seconds_out) *seconds_out = 0;
+  if (launches_out) *launches_out = 0;
+  return fail(ctx, RMHMC_ERR_UNSUPPORTED, "no kernels in the CPU oracle");
+}
+
+void rmhmc_destroy(rmhmc_ctx *ctx) {
+  if (!ctx) return;
+  if (ctx->chains) {
+    for (int64_t c = 0; c < ctx->n; c++) {
+      struct chain *ch = &ctx->chains[c];
+      point_free(&ch->cur); point_free(&ch->trj); work_free(&ch->k);
+      free(ch->p); free(ch->p0); free(ch->z);
+    }
+    free(ctx->chains);
+  }
+  free(ctx->X); free(ctx->t); free(ctx);
+}

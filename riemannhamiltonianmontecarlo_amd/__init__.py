@@ -1,0 +1,9 @@
+"""MI355X-native RMHMC hot path (Bayesian logistic regression).
+
+Host side of the C-ABI in include/rmhmc.h; mirrors the reference's
+``code/rmhmc.py`` interface.  See DESIGN.md.
+"""
+from .rmhmc import RMHMC  # noqa: F401
+from . import tools, data  # noqa: F401
+
+__all__ = ["RMHMC", "tools", "data"]

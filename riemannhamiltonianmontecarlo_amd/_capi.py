@@ -1,0 +1,215 @@
+"""ctypes binding of the C-ABI declared in include/rmhmc.h.
+
+``RmhmcLib(path)`` binds any shared library exporting that ABI.  The product
+uses it with the HIP library only (``load_hip_library``), which raises if the
+extension is missing or cannot run — there is no CPU fallback.  The test-suite
+binds the CPU oracle with the same class to diff results.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+F64 = 0
+FLAG_MOMENTUM_LT = 1 << 0
+FLAG_GUARDS = 1 << 1
+COMPAT = FLAG_MOMENTUM_LT | FLAG_GUARDS
+FLAG_ORACLE_LITERAL = 1 << 8
+
+ST_NOT_PD, ST_NONFINITE, ST_GUARD_P, ST_GUARD_W = 1, 2, 4, 8
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG, "csrc", "librmhmc_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+# every symbol include/rmhmc.h declares, with its signature
+SIGNATURES = {
+    "rmhmc_version": (C.c_char_p, []),
+    "rmhmc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_uint32]),
+    "rmhmc_destroy": (None, [C.c_void_p]),
+    "rmhmc_last_error": (C.c_char_p, [C.c_void_p]),
+    "rmhmc_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "rmhmc_set_data": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double]),
+    "rmhmc_log_posterior": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "rmhmc_metric": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "rmhmc_metric_terms": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "rmhmc_leapfrog": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, _ip, _ip, C.c_int32, _dp, _ip]),
+    "rmhmc_transition": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, C.c_int32,
+                                   _ip, _ip, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "rmhmc_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64,
+                               C.c_int64, _dp, _dp, _lp, _lp, _dp]),
+    "rmhmc_chains_init": (C.c_int, [C.c_void_p, _dp, C.c_uint64, C.c_int64, C.c_int32, C.c_double, C.c_int32]),
+    "rmhmc_chains_run": (C.c_int, [C.c_void_p, C.c_int64]),
+    "rmhmc_chains_state": (C.c_int, [C.c_void_p, _dp, _lp, _lp]),
+    "rmhmc_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _lp]),
+}
+
+
+class RmhmcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rmhmc error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a, typ=_dp):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class RmhmcLib:
+    """A loaded library exporting the rmhmc C-ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError("rmhmc library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+        self.path = path
+        self.lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.lib, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+
+    def version(self):
+        return self.lib.rmhmc_version().decode()
+
+    def context(self, M, D, n_chains=1, flags=COMPAT, device=0):
+        return Context(self, M, D, n_chains, flags, device)
+
+
+class Context:
+    """One opaque rmhmc_ctx: M data rows, D dims, n_chains chains on one device."""
+
+    def __init__(self, rl, M, D, n_chains, flags, device):
+        self.rl, self.lib = rl, rl.lib
+        self.M, self.D, self.n, self.flags = int(M), int(D), int(n_chains), int(flags)
+        self._h = C.c_void_p()
+        rc = self.lib.rmhmc_create(C.byref(self._h), device, self.M, self.D, self.n, F64, self.flags)
+        if rc != 0:
+            raise RmhmcError(rc, self.lib.rmhmc_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            self.lib.rmhmc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RmhmcError(rc, self.lib.rmhmc_last_error(self._h).decode())
+
+    def device_info(self):
+        buf = C.create_string_buffer(512)
+        self._ck(self.lib.rmhmc_device_info(self._h, buf, 512))
+        return buf.value.decode()
+
+    def set_data(self, XX, t, alpha=100.0):
+        XX = _f64(XX)
+        t = _f64(t).ravel()
+        if XX.shape != (self.M, self.D) or t.shape != (self.M,):
+            raise ValueError("XX must be (%d,%d) and t (%d,)" % (self.M, self.D, self.M))
+        self._ck(self.lib.rmhmc_set_data(self._h, _ptr(XX), _ptr(t), float(alpha)))
+
+    # ---- unit entry points -------------------------------------------------
+    def log_posterior(self, w):
+        w = _f64(w, (self.n, self.D))
+        out = np.empty(self.n)
+        self._ck(self.lib.rmhmc_log_posterior(self._h, _ptr(w), _ptr(out)))
+        return out
+
+    def metric(self, w):
+        w = _f64(w, (self.n, self.D))
+        G = np.empty((self.n, self.D, self.D)); hld = np.empty(self.n); g = np.empty((self.n, self.D))
+        self._ck(self.lib.rmhmc_metric(self._h, _ptr(w), _ptr(G), _ptr(hld), _ptr(g)))
+        return G, hld, g
+
+    def metric_terms(self, w, p=None):
+        w = _f64(w, (self.n, self.D))
+        tr = np.empty((self.n, self.D))
+        q = None
+        if p is not None:
+            p = _f64(p, (self.n, self.D))
+            q = np.empty((self.n, self.D))
+        self._ck(self.lib.rmhmc_metric_terms(self._h, _ptr(w), _ptr(p), _ptr(tr), _ptr(q)))
+        return tr, q
+
+    def leapfrog(self, w, p, eps, direction, nsteps, K=4):
+        w = _f64(w, (self.n, self.D)).copy(); p = _f64(p, (self.n, self.D)).copy()
+        d = np.ascontiguousarray(np.broadcast_to(direction, (self.n,)), dtype=np.int32)
+        ns = np.ascontiguousarray(np.broadcast_to(nsteps, (self.n,)), dtype=np.int32)
+        hld = np.empty(self.n); st = np.zeros(self.n, dtype=np.int32)
+        self._ck(self.lib.rmhmc_leapfrog(self._h, _ptr(w), _ptr(p), float(eps), _ptr(d, _ip), _ptr(ns, _ip), int(K),
+                                         _ptr(hld), _ptr(st, _ip)))
+        return w, p, hld, st
+
+    def transition(self, w, z, u_len, g_dir, u_acc, L=6, eps=0.5, K=4):
+        n, D = self.n, self.D
+        w = _f64(w, (n, D)).copy()
+        z = _f64(z, (n, D)); u_len = _f64(u_len, (n,)); g_dir = _f64(g_dir, (n,)); u_acc = _f64(u_acc, (n,))
+        acc = np.zeros(n, dtype=np.int32); ns = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+        Hc = np.empty(n); Hp = np.empty(n); wp = np.empty((n, D)); pp = np.empty((n, D)); hp = np.empty(n)
+        self._ck(self.lib.rmhmc_transition(self._h, _ptr(w), _ptr(z), _ptr(u_len), _ptr(g_dir), _ptr(u_acc), int(L),
+                                           float(eps), int(K), _ptr(acc, _ip), _ptr(ns, _ip), _ptr(Hc), _ptr(Hp),
+                                           _ptr(wp), _ptr(pp), _ptr(hp), _ptr(st, _ip)))
+        return dict(w=w, accepted=acc, nsteps=ns, H_cur=Hc, H_prop=Hp, w_prop=wp, p_prop=pp, hld_prop=hp, status=st)
+
+    # ---- bulk entry points -------------------------------------------------
+    def sample(self, n_iter, burn_in, L=6, eps=0.5, K=4, seed=0, chain_offset=0, theta0=None):
+        n, D = self.n, self.D
+        S = int(n_iter) - int(burn_in)
+        if S <= 0:
+            raise ValueError("BurnIn must be < NumOfIterations")
+        th = None if theta0 is None else _f64(np.broadcast_to(theta0, (n, D)))
+        samples = np.empty((n, S, D)); acc = np.zeros(n, dtype=np.int64); steps = np.zeros(n, dtype=np.int64)
+        secs = C.c_double(0.0)
+        self._ck(self.lib.rmhmc_sample(self._h, int(n_iter), int(burn_in), int(L), float(eps), int(K), int(seed),
+                                       int(chain_offset), _ptr(th), _ptr(samples), _ptr(acc, _lp), _ptr(steps, _lp),
+                                       C.cast(C.byref(secs), _dp)))
+        return samples, acc, steps, secs.value
+
+    def chains_init(self, theta0=None, seed=0, chain_offset=0, L=6, eps=0.5, K=4):
+        th = None if theta0 is None else _f64(np.broadcast_to(theta0, (self.n, self.D)))
+        self._ck(self.lib.rmhmc_chains_init(self._h, _ptr(th), int(seed), int(chain_offset), int(L), float(eps), int(K)))
+
+    def chains_run(self, n_steps):
+        self._ck(self.lib.rmhmc_chains_run(self._h, int(n_steps)))
+
+    def chains_state(self):
+        w = np.empty((self.n, self.D)); it = np.zeros(self.n, dtype=np.int64); acc = np.zeros(self.n, dtype=np.int64)
+        self._ck(self.lib.rmhmc_chains_state(self._h, _ptr(w), _ptr(it, _lp), _ptr(acc, _lp)))
+        return w, it, acc
+
+    def kernel_time(self, which):
+        s = C.c_double(0.0); k = C.c_int64(0)
+        self._ck(self.lib.rmhmc_kernel_time(self._h, which.encode(), C.cast(C.byref(s), _dp), C.cast(C.byref(k), _lp)))
+        return s.value, k.value
+
+
+_hip = None
+
+
+def load_hip_library():
+    """The product library (HIP kernels for gfx950).  Raises when it is not built."""
+    global _hip
+    if _hip is None:
+        _hip = RmhmcLib(HIP_LIB_PATH)
+    return _hip

@@ -1,0 +1,60 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "librmhmc_oracle.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+from riemannhamiltonianmontecarlo_amd import _capi  # noqa: E402
+from riemannhamiltonianmontecarlo_amd.data import synthetic_logreg  # noqa: E402
+
+
+def _build_oracle():
+    import subprocess
+    src = os.path.join(ROOT, "oracle", "rmhmc_oracle.c")
+    if (not os.path.exists(ORACLE_LIB)) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle bound through the same ctypes class as the product (test infrastructure)."""
+    _build_oracle()
+    return _capi.RmhmcLib(ORACLE_LIB)
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library; GPU tests fail loudly if it is not built."""
+    return _capi.load_hip_library()
+
+
+TAPES = ["pima", "australian", "german", "heart", "syn_m1000_d8", "syn_m50_d5_L1", "syn_m300_d20", "syn_m203_d33",
+         "syn_m10000_d64_L1", "guard_w"]
+
+
+def load_tape(name):
+    """Returns (XX, t, tape dict) for a golden transition tape captured from the reference."""
+    g = dict(np.load(os.path.join(GOLDEN, "tape_%s.npz" % name)))
+    if name in ("pima", "australian", "german", "heart"):
+        d = np.load(os.path.join(GOLDEN, "data_%s.npz" % name))
+        XX, t = d["XX"], d["t"]
+    else:
+        XX, t = synthetic_logreg(int(g["M"]), int(g["D"]), int(g["data_seed"]))
+        if "x_scale" in g:
+            XX = XX * float(g["x_scale"])
+    return XX, t, g
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
