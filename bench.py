@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the RMHMC hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the whole batch: every chain executes ONE generalised
+leapfrog step (rmhmc.py:96-163), including the transition bookkeeping (momentum draw, Hamiltonians,
+accept/reject) of the chains whose trajectory starts or ends on that step.  `value` is leapfrog
+steps per second summed over all chains and GPUs, with X, t and the chain state resident in HBM.
+
+Workloads (BASELINE.json configs):
+  c3  8192 chains/GPU, D=64, M=10000  (default; the configuration the north-star target is quoted
+      on; with --gpus 8 it is config 4: 65536 chains sharded 8192 per GPU, weak scaling)
+  c2  1024 chains, D=8, M=1000
+  c1  bundled australian data (M=690, D=15), 1 chain
+
+Extra objects in the JSON line: "roofline" (dominant kernel = metric assembly, timed with HIP events
+on the library's stream inside the timed region) and "cpu_baseline" (the CPU oracle timed on the
+host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md (spec; 6.3e12 achievable, 5.94e12 measured by tools/mfma_probe)
+FP64_MFMA_PEAK = 78.6e12  # flop/s dense fp64 matrix (spec); tools/mfma_probe measures 75.1e12
+
+WORKLOADS = {
+    "c3": dict(chains=8192, D=64, M=10000, desc="BASELINE config 3/4: 8192 chains per GPU, D=64, M=10000 synthetic logistic regression"),
+    "c2": dict(chains=1024, D=8, M=1000, desc="BASELINE config 2: 1024 chains, D=8, M=1000 synthetic logistic regression"),
+    "c1": dict(chains=1, D=15, M=690, desc="BASELINE config 1: bundled australian data, 1 chain"),
+}
+
+
+def load_problem(name):
+    from riemannhamiltonianmontecarlo_amd.data import synthetic_logreg
+    wl = WORKLOADS[name]
+    if name == "c1":
+        d = np.load(os.path.join(ROOT, "tests", "golden", "data_australian.npz"))
+        return d["XX"], d["t"]
+    return synthetic_logreg(wl["M"], wl["D"], 0)
+
+
+def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0):
+    """Time the CPU oracle (oracle/librmhmc_oracle.so, the C restatement of rmhmc.py — kind "port") on
+    the host cores with a bounded sample of the same workload: `cores` chains, a few global steps."""
+    from riemannhamiltonianmontecarlo_amd import _capi
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.ORACLE_LIB):
+        return None
+    oracle = _capi.RmhmcLib(ge.ORACLE_LIB)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    M, D = XX.shape
+    n = cores
+    with oracle.context(M, D, n, flags=flags) as ctx:
+        ctx.set_data(XX, t)
+        ctx.chains_init(seed=1, L=L, eps=eps, K=K)
+        t0 = time.perf_counter(); ctx.chains_run(1); dt1 = time.perf_counter() - t0
+        steps = int(max(1, min(200, budget_s / max(dt1, 1e-6))))
+        t0 = time.perf_counter(); ctx.chains_run(steps); dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d leapfrog steps of the same (M=%d, D=%d) workload, matrix-free C oracle, OpenMP over chains, %.1f s"
+                      % (n, steps, M, D, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--compat", type=int, default=0, help="1: reference-compatible momentum (L'z) and guards; 0: corrected (default, see DESIGN.md)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from riemannhamiltonianmontecarlo_amd import _capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU fallback")
+
+    wl = WORKLOADS[args.workload]
+    n = args.chains or wl["chains"]
+    XX, t = load_problem(args.workload)
+    M, D = XX.shape
+    L, eps, K = 6, 0.5, 4  # reference defaults, rmhmc.py:13
+    flags = _capi.COMPAT if args.compat else 0
+
+    lib = _capi.load_hip_library()  # raises if the extension is not built
+    ctx = lib.context(M, D, n, flags=flags, device=local_rank)
+    ctx.set_data(XX, t)
+    ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.chains_run(args.warmup)
+    ctx.kernel_time("enable"); ctx.kernel_time("reset")
+    barrier()
+    t0 = time.perf_counter()
+    ctx.chains_run(args.steps)   # synchronous: returns when the device is idle
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kt = {k: ctx.kernel_time(k) for k in ("assemble", "leverage", "rowpass", "xtr", "factor", "small", "total")}
+    ctx.kernel_time("disable")
+    w_end, iters, acc = ctx.chains_state()
+    finite = bool(np.isfinite(w_end).all())
+    acc_rate = float(acc.sum()) / max(1.0, float(iters.sum()))
+
+    if world > 1:
+        # the one exchange of the sharded path: gather the chain positions at write-out (RCCL over xGMI)
+        wt = torch.from_numpy(w_end).cuda()
+        gathered = [torch.empty_like(wt) for _ in range(world)] if rank == 0 else None
+        dist.gather(wt, gathered, dst=0)
+        if rank == 0:
+            finite = finite and all(bool(torch.isfinite(g).all()) for g in gathered)
+
+    if rank == 0:
+        total_steps = world * n * args.steps
+        value = total_steps / elapsed
+        bytes_step = 80.0 * M * D          # (2K+2) passes over X per chain per leapfrog step, K=4
+        flops_step = 6.0 * M * D * D + 40.0 * M * D + 2.0 * D ** 3
+        a_s, a_n = kt["assemble"]
+        pass_bytes = 8.0 * M * D * n       # one assembly launch = one pass over X for every chain on this GPU
+        roof = None
+        if a_n > 0:
+            a_avg = a_s / a_n
+            achieved = pass_bytes / a_avg
+            roof = {"bound": "hbm", "kernel": "k_assemble (X' diag(v) X on fp64 MFMA)", "achieved": achieved / 1e9,
+                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                    "avg_launch_ms": a_avg * 1e3, "launches": a_n,
+                    "mfma_tflops": (n * M * (D / 16.0) * (D / 16.0 + 1) / 2 * 2048.0 / 4.0) / a_avg / 1e12,
+                    "mfma_frac": (n * M * (D / 16.0) * (D / 16.0 + 1) / 2 * 2048.0 / 4.0) / a_avg / FP64_MFMA_PEAK,
+                    "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
+                    "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
+                    "note": "achieved = algorithmic bytes (8*M*D per chain per pass) / measured launch time; X is shared by all "
+                            "chains and cache resident, so DRAM traffic is far below the algorithmic bytes (see DESIGN.md)"}
+            pmc = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+            if os.path.exists(pmc):
+                roof["traffic"] = json.load(open(pmc)).get("assemble_bytes_per_launch")
+        out = {
+            "metric": "leapfrog-steps/sec (whole node)", "value": value, "unit": "leapfrog-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
+                       "D": D, "M": M, "leapfrog_L": L, "step_size": eps, "fixed_point_K": K,
+                       "compat": bool(args.compat), "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": roof,
+            "kernel_seconds": {k: {"seconds": v[0], "launches": v[1]} for k, v in kt.items()},
+            "all_finite": finite, "acceptance_rate": acc_rate,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(XX, t, flags, L, eps, K)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,8 +208,16 @@ _hip = None
 
 
 def load_hip_library():
-    """The product library (HIP kernels for gfx950).  Raises when it is not built."""
+    """The product library (HIP kernels for gfx950).  Raises when it is not built.
+
+    PyTorch (used for device plumbing and torch.distributed) bundles its own HIP runtime with the
+    same SONAME as the system one.  Importing torch BEFORE dlopen-ing the library makes both share
+    that single runtime; the other order would put two HIP/HSA stacks in one process."""
     global _hip
     if _hip is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip = RmhmcLib(HIP_LIB_PATH)
     return _hip

@@ -1,0 +1,707 @@
+// kernels.hip.h — gfx950 device code of the RMHMC hot path (included by rmhmc_hip.hip).
+//
+// Algorithm: matrix-free generalised leapfrog for Bayesian logistic regression,
+// following emilemathieu/RiemannHamiltonianMonteCarlo code/rmhmc.py:37-191.
+// One chain per wavefront in every per-chain kernel; X is shared by all chains.
+//
+// Data layout in HBM (all float64):
+//   Xr  [Mp][DP]   design matrix, row-major, zero padded (Mp = M rounded up to 64, DP = D up to 16*NB)
+//   Xt  [DP][Mp]   its transpose (lane = data row kernels read it coalesced)
+//   per chain c: vectors [c][DP], matrices [c][DP][DP], row vectors [c][Mp]
+// Padded entries of every vector/matrix are kept at exactly 0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define RM_LD 65            // LDS leading dimension of the per-chain DxD matrix (65: conflict-free columns)
+#define RM_PI2 6.283185307179586476925286766559
+
+struct DevData {
+  const double* Xr;
+  const double* Xt;
+  const double* t;
+  int M, Mp, D, DP, nblk;   // nblk = Mp/64
+  double inv_alpha;
+  double log_prior_const;   // -0.5*log(2*pi*alpha)
+};
+
+// point record: everything the sampler needs at a position w (rmhmc.py:50-77 / :134-156)
+struct Rec {
+  double *w, *grad, *tr, *L, *Ginv, *ljl, *hld;
+};
+
+struct Chains {
+  Rec cur, trj;
+  double *p, *p0, *Hcur, *Hprop, *tau;
+  int *steps_left, *phase, *status, *nsteps_last;
+  long long *iter, *accepted, *steps_done;
+  // scratch
+  double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv1, *ljl_part;
+  int n;
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+// sum over the 16 lanes that share lane>>4
+__device__ __forceinline__ double row16_sum(double x) {
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+// sum over the 4 lanes that share lane&15
+__device__ __forceinline__ double col4_sum(double x) {
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG — same stream specification as oracle/rmhmc_oracle.c:
+// key = seed, counter = (chain lo, chain hi, iteration, block); blocks 0..ceil(D/2)-1 -> momentum
+// normals (Box-Muller), block 0x40000000 -> (u_len, u_acc), block 0x40000001 -> g_dir.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_t iter, uint32_t block, double& U0, double& U1) {
+  uint32_t c[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), iter, block};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  U0 = u53(c[0], c[1]);
+  U1 = u53(c[2], c[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1  row pass (lane = data row).  64 rows of X live in registers and are re-used for `cpg`
+// chains; the chain's vectors are wave-uniform (scalar loads).  Replaces the f/p/v blocks of
+// rmhmc.py:51-53,99-100,116-118,134-136,166-168 and the c = v(1-2p) factor of :67,:148.
+//   RP_V : out0 = v_n = p(1-p),  p = 1/(1+e^-f),  f = x_n.wq                 (rmhmc.py:116-118)
+//   RP_F : out0 = v_n, out1 = t_n - e^f/(1+e^f) (rmhmc.py:140), ljl partial  (rmhmc.py:167-168)
+//   RP_S : out0 = c_n (x_n.uq)^2, out1 = c_n, with c from f = x_n.wq        (rmhmc.py:104-107)
+// ---------------------------------------------------------------------------------------------
+enum { RP_V = 0, RP_F = 1, RP_S = 2 };
+
+template <int DP, int MODE>
+__global__ __launch_bounds__(64) void k_rowpass(DevData dd, int n_chains, int cpg, const int* __restrict__ phase,
+                                                const double* __restrict__ wq, const double* __restrict__ uq,
+                                                double* __restrict__ out0, double* __restrict__ out1,
+                                                double* __restrict__ ljl_part) {
+  const int lane = threadIdx.x;
+  const int blk = blockIdx.x;
+  const size_t n = (size_t)blk * 64 + lane;
+  double x[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) x[d] = dd.Xt[(size_t)d * dd.Mp + n];
+  const double tn = dd.t[n];
+  const bool valid = n < (size_t)dd.M;
+  const int c0 = blockIdx.y * cpg;
+  const int c1 = min(c0 + cpg, n_chains);
+  for (int c = c0; c < c1; ++c) {
+    if (phase[c] != 1) continue;  // wave-uniform
+    const double* __restrict__ w = wq + (size_t)c * DP;
+    double f = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) f = fma(x[d], w[d], f);
+    const double em = exp(-f);
+    const double p = 1.0 / (1.0 + em);
+    const double v = p * (1.0 - p);
+    const size_t o = (size_t)c * dd.Mp + n;
+    if (MODE == RP_V) {
+      out0[o] = v;
+    } else if (MODE == RP_F) {
+      const double ef = exp(f);
+      out0[o] = v;
+      out1[o] = tn - ef / (1.0 + ef);
+      double term = valid ? (f * tn - log(1.0 + ef)) : 0.0;
+      term = wave_sum(term);
+      if (lane == 0) ljl_part[(size_t)c * dd.nblk + blk] = term;
+    } else {
+      const double* __restrict__ u = uq + (size_t)c * DP;
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) s = fma(x[d], u[d], s);
+      const double cn = v * (1.0 - 2.0 * p);
+      out0[o] = cn * s * s;
+      out1[o] = cn;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  metric assembly  G = X' diag(v) X + I/alpha  on the fp64 matrix cores (rmhmc.py:57,119,137),
+// optionally fused with the likelihood gradient X' r - w/alpha (rmhmc.py:100,140).
+// One chain per wavefront.  v_mfma_f64_16x16x4_f64: A[i][k], B[k][j] one f64 per lane with
+// i/j = lane&15, k = lane>>4; D[(lane>>4)+4r][lane&15] in accumulator register r.
+// Column permutation: tile index I in [0,NB) and in-tile index i map to column NB*i + I, so a
+// lane loads NB *contiguous* doubles of its data row (a wave reads 4 rows = 4*DP*8 contiguous
+// bytes per step) and the same registers serve as A (scaled by v_n) and B operands.
+// Only tiles I<=J are computed (G is symmetric): NB(NB+1)/2 MFMAs per 4 data rows.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool GRAD>
+__global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, const int* __restrict__ phase,
+                                                  const double* __restrict__ vrow, const double* __restrict__ rrow,
+                                                  const double* __restrict__ wq, double* __restrict__ Gq,
+                                                  double* __restrict__ grad) {
+  constexpr int DP = 16 * NB;
+  constexpr int NT = NB * (NB + 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chains) return;
+  if (phase[c] != 1) return;
+  const int rr = lane >> 4, ci = lane & 15;
+  const double* __restrict__ xp = dd.Xr + (size_t)rr * DP + NB * ci;
+  const double* __restrict__ vp = vrow + (size_t)c * dd.Mp + rr;
+  const double* __restrict__ rp = GRAD ? (rrow + (size_t)c * dd.Mp + rr) : nullptr;
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  double gacc[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) gacc[I] = 0.0;
+
+  // Mp is a multiple of 64: 4 chunks of 4 data rows per trip, loads of all four issued up front
+  for (int n1 = 0; n1 < dd.Mp; n1 += 16)
+#pragma unroll
+  for (int n0 = n1; n0 < n1 + 16; n0 += 4) {
+    double xb[NB], xa[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) xb[I] = xp[(size_t)n0 * DP + I];
+    const double vv = vp[n0];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) xa[I] = vv * xb[I];
+    if (GRAD) {
+      const double rv = rp[n0];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) gacc[I] = fma(rv, xb[I], gacc[I]);
+    }
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) {
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[I], xb[J], acc[t], 0, 0, 0);
+        ++t;
+      }
+  }
+  // epilogue: scatter the permuted tiles into the natural row-major DPxDP matrix (+ I/alpha)
+  double* __restrict__ G = Gq + (size_t)c * DP * DP;
+  int t = 0;
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int J = I; J < NB; ++J) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = NB * (rr + 4 * r) + I;
+        const int col = NB * ci + J;
+        double val = acc[t][r];
+        if (row == col) val += dd.inv_alpha;
+        G[row * DP + col] = val;
+        if (I != J) G[col * DP + row] = val;
+      }
+      ++t;
+    }
+  if (GRAD) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      const double g = col4_sum(gacc[I]);
+      const int d = NB * ci + I;
+      if (rr == 0 && d < dd.D) grad[(size_t)c * DP + d] = g - wq[(size_t)c * DP + d] * dd.inv_alpha;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  q = X' r  for one row vector per chain (the contraction u' dG_d u = sum_n c_n (x_n.u)^2 x_nd
+// of rmhmc.py:104-107 once r = c (x.u)^2 is known).  One chain per wavefront, same lane layout as
+// k_assemble (4 rows x 16 column groups per step).
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void k_xtr(DevData dd, int n_chains, const int* __restrict__ phase,
+                                             const double* __restrict__ rrow, double* __restrict__ out) {
+  constexpr int DP = 16 * NB;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chains) return;
+  if (phase[c] != 1) return;
+  const int rr = lane >> 4, ci = lane & 15;
+  const double* __restrict__ xp = dd.Xr + (size_t)rr * DP + NB * ci;
+  const double* __restrict__ rp = rrow + (size_t)c * dd.Mp + rr;
+  double acc[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) acc[I] = 0.0;
+#pragma unroll 8
+  for (int n0 = 0; n0 < dd.Mp; n0 += 4) {
+    const double rv = rp[n0];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) acc[I] = fma(rv, xp[(size_t)n0 * DP + I], acc[I]);
+  }
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const double g = col4_sum(acc[I]);
+    const int d = NB * ci + I;
+    if (rr == 0 && d < dd.D) out[(size_t)c * DP + d] = g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4  leverage pass on the matrix cores: h_n = x_n' G^-1 x_n for every data row, then
+//       tr_d   = sum_n c_n h_n x_nd          (= tr(G^-1 dG/dw_d),      rmhmc.py:67-77,148-156)
+//       last_d = sum_n cs2_n x_nd            (= u' dG/dw_d u,          rmhmc.py:158-161)
+// Y = X * Ghat with Ghat the block-upper-triangular fold of the symmetric G^-1 (off-diagonal
+// blocks doubled) so only NB(NB+1)/2 blocks are multiplied; h = rowsum(Y .* X).
+// Blocks use the same column permutation as k_assemble (block I = columns NB*m + I).
+// Per 16 data rows: A operand X[n0+(lane&15)][NB*(4s+(lane>>4)) + I]  (s = 0..3),
+//                   B operand Ghat[NB*(4s+(lane>>4)) + I][NB*(lane&15) + J]  (held in registers),
+//                   Y_J[r] = Y[n0+(lane>>4)+4r][NB*(lane&15)+J].
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, const int* __restrict__ phase,
+                                                  const double* __restrict__ Ginv, const double* __restrict__ crow,
+                                                  const double* __restrict__ cs2row, double* __restrict__ tr,
+                                                  double* __restrict__ last) {
+  constexpr int DP = 16 * NB;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chains) return;
+  if (phase[c] != 1) return;
+  const int rr = lane >> 4, ci = lane & 15;
+  const double* __restrict__ Gi = Ginv + (size_t)c * DP * DP;
+  // B operands
+  double Bv[NB][4][NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        const int row = NB * (4 * s + rr) + I, col = NB * ci + J;
+        Bv[I][s][J] = (J >= I) ? Gi[row * DP + col] * (I == J ? 1.0 : 2.0) : 0.0;
+      }
+  const double* __restrict__ xa_p = dd.Xr + (size_t)ci * DP + NB * rr;       // A layout: row n0+ci, col NB*(4s+rr)+I
+  const double* __restrict__ xc_p = dd.Xr + (size_t)rr * DP + NB * ci;       // C layout: row n0+rr+4r, col NB*ci+J
+  const double* __restrict__ cp = crow + (size_t)c * dd.Mp + rr;
+  const double* __restrict__ sp = cs2row + (size_t)c * dd.Mp + rr;
+  double tracc[NB], lacc[NB];
+#pragma unroll
+  for (int J = 0; J < NB; ++J) { tracc[J] = 0.0; lacc[J] = 0.0; }
+
+  for (int n0 = 0; n0 < dd.Mp; n0 += 16) {
+    double A[4][NB], Xc[4][NB];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int I = 0; I < NB; ++I) A[s][I] = xa_p[(size_t)n0 * DP + NB * 4 * s + I];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) Xc[r][J] = xc_p[(size_t)(n0 + 4 * r) * DP + J];
+    d4 Y[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      Y[J] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int I = 0; I <= J; ++I)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Y[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s][I], Bv[I][s][J], Y[J], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double hp = 0.0;
+#pragma unroll
+      for (int J = 0; J < NB; ++J) hp = fma(Y[J][r], Xc[r][J], hp);
+      const double h = row16_sum(hp);
+      const double ch = cp[n0 + 4 * r] * h;
+      const double cs = sp[n0 + 4 * r];
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        tracc[J] = fma(ch, Xc[r][J], tracc[J]);
+        lacc[J] = fma(cs, Xc[r][J], lacc[J]);
+      }
+    }
+  }
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+    const double a = col4_sum(tracc[J]);
+    const double b = col4_sum(lacc[J]);
+    const int d = NB * ci + J;
+    if (rr == 0 && d < dd.D) {
+      tr[(size_t)c * DP + d] = a;
+      last[(size_t)c * DP + d] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense kernels: one chain per wavefront (64 threads per block), DxD matrix in LDS.
+// ---------------------------------------------------------------------------------------------
+// lower Cholesky in place (left-looking; lane i owns row i).  np.linalg.cholesky, rmhmc.py:60,171.
+// A pivot <=0 or NaN yields NaN everywhere downstream (=> H is NaN => the proposal is rejected).
+__device__ __forceinline__ int chol_lds(double* A, int D, int lane) {
+  int bad = 0;
+  for (int j = 0; j < D; ++j) {
+    double s = 0.0;
+    if (lane >= j && lane < D) {
+      s = A[lane * RM_LD + j];
+      for (int k = 0; k < j; ++k) s = fma(-A[lane * RM_LD + k], A[j * RM_LD + k], s);
+    }
+    const double sjj = __shfl(s, j, 64);
+    if (!(sjj > 0.0)) bad = 1;
+    const double ljj = sqrt(sjj);
+    __syncthreads();
+    if (lane >= j && lane < D) A[lane * RM_LD + j] = (lane == j) ? ljj : s / ljj;
+    __syncthreads();
+  }
+  return bad;
+}
+// x = (L L')^-1 b ; lane i holds b_i on entry and x_i on return
+__device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane, double b) {
+  for (int k = 0; k < D; ++k) {  // forward, column oriented
+    const double yk = __shfl(b, k, 64) / L[k * RM_LD + k];
+    if (lane == k) b = yk;
+    else if (lane > k && lane < D) b = fma(-L[lane * RM_LD + k], yk, b);
+  }
+  for (int k = D - 1; k >= 0; --k) {  // backward with L'
+    const double xk = __shfl(b, k, 64) / L[k * RM_LD + k];
+    if (lane == k) b = xk;
+    else if (lane < k) b = fma(-L[k * RM_LD + lane], xk, b);
+  }
+  return b;
+}
+
+__device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict__ G, int D, int DP, int lane) {
+  for (int i = 0; i < D; ++i)
+    if (lane < D) A[i * RM_LD + lane] = G[i * DP + lane];
+  __syncthreads();
+}
+
+// position fixed point, first iterate (rmhmc.py:113-122 with FixedIter = 0): G(Pw^0) = G(w) is the
+// factor already stored in the trajectory record, so u = u0 and Pw^1 = w + tau*eps*u0.
+__global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps) {
+  __shared__ double A[64 * RM_LD];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  load_mat_lds(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
+  const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
+  const double u0 = cholsolve_lds(A, D, lane, pb);
+  if (lane < D) {
+    ch.u0[(size_t)c * DP + lane] = u0;
+    ch.wq[(size_t)c * DP + lane] = ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * eps * u0;
+  }
+}
+
+// position fixed point, iterate k>=1 (rmhmc.py:116-122): factor G(Pw^k), solve, update Pw.
+__global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, double eps) {
+  __shared__ double A[64 * RM_LD];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
+  const int bad = chol_lds(A, D, lane);
+  const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
+  const double u = cholsolve_lds(A, D, lane, pb);
+  if (lane < D)
+    ch.wq[(size_t)c * DP + lane] =
+        ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * (eps * 0.5) * (ch.u0[(size_t)c * DP + lane] + u);
+  if (bad && lane == 0) ch.status[c] |= 1;  // RMHMC_ST_NOT_PD
+}
+
+// accept the position iterate as the new w and apply the position guard (rmhmc.py:123-130)
+__global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int guards) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  double w = (lane < D) ? ch.wq[(size_t)c * DP + lane] : 0.0;
+  if (guards) {
+    const double nw = sqrt(wave_sum(w * w));
+    if (nw > 10.0) {
+      w /= nw * 3.0;
+      if (lane == 0) ch.status[c] |= 8;  // RMHMC_ST_GUARD_W
+    }
+  }
+  if (lane < D) {
+    ch.trj.w[(size_t)c * DP + lane] = w;
+    ch.wq[(size_t)c * DP + lane] = w;
+  }
+}
+
+// new point: factor G(w), half log-determinant, explicit inverse, log joint, and u = G^-1 p
+// (rmhmc.py:137-138,158,166-171).  Lane j solves (L L') x = e_j: column j of G^-1.
+__global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch) {
+  __shared__ double A[64 * RM_LD];
+  __shared__ double Y[64 * RM_LD];
+  const int D = dd.D, DP = dd.DP;
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
+  const int bad = chol_lds(A, D, lane);
+  // half log det = sum log diag(L)   (rmhmc.py:171,175)
+  const double ld = (lane < D) ? log(A[lane * RM_LD + lane]) : 0.0;
+  const double hld = wave_sum(ld);
+  // inverse: forward then backward substitution, lane j owns right-hand side e_j (column j of Y)
+  for (int i = 0; i < D; ++i) {
+    double s = (i == lane) ? 1.0 : 0.0;
+    for (int k = 0; k < i; ++k) s = fma(-A[i * RM_LD + k], Y[k * RM_LD + lane], s);
+    Y[i * RM_LD + lane] = s / A[i * RM_LD + i];
+  }
+  for (int i = D - 1; i >= 0; --i) {
+    double s = Y[i * RM_LD + lane];
+    for (int k = i + 1; k < D; ++k) s = fma(-A[k * RM_LD + i], Y[k * RM_LD + lane], s);
+    Y[i * RM_LD + lane] = s / A[i * RM_LD + i];
+  }
+  __syncthreads();
+  // store L (lower, zeros above) and the symmetrised inverse
+  double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
+  double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  for (int i = 0; i < D; ++i)
+    if (lane < D) {
+      Lg[i * DP + lane] = (lane <= i) ? A[i * RM_LD + lane] : 0.0;
+      Gi[i * DP + lane] = 0.5 * (Y[i * RM_LD + lane] + Y[lane * RM_LD + i]);
+    }
+  // u = G^-1 p
+  double u = 0.0;
+  for (int j = 0; j < D; ++j) {
+    const double pj = ch.p[(size_t)c * DP + j];
+    if (lane < D) u = fma(0.5 * (Y[j * RM_LD + lane] + Y[lane * RM_LD + j]), pj, u);
+  }
+  if (lane < D) ch.uq[(size_t)c * DP + lane] = u;
+  // log joint = sum of the row-block partials + Gaussian prior (rmhmc.py:166-169, tools.py:10-14)
+  double part = 0.0;
+  for (int b = lane; b < dd.nblk; b += 64) part += ch.ljl_part[(size_t)c * dd.nblk + b];
+  const double wl = (lane < D) ? ch.trj.w[(size_t)c * DP + lane] : 0.0;
+  part += (lane < D) ? (dd.log_prior_const - wl * wl * 0.5 * dd.inv_alpha) : 0.0;
+  const double ljl = wave_sum(part);
+  if (lane == 0) {
+    ch.trj.hld[c] = hld;
+    ch.trj.ljl[c] = ljl;
+    if (bad) ch.status[c] |= 1;
+  }
+}
+
+// u = G^-1 v for the momentum fixed point (rmhmc.py:104); src = p (first iterate) or PM
+__global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, const double* __restrict__ src) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  double u = 0.0;
+  for (int j = 0; j < D; ++j) {
+    const double sj = src[(size_t)c * DP + j];
+    if (lane < D) u = fma(Gi[j * DP + lane], sj, u);  // symmetric: row j read coalesced
+  }
+  if (lane < D) ch.uq[(size_t)c * DP + lane] = u;
+}
+
+// PM = p + tau*eps/2 * (grad - tr/2 + q/2)   (rmhmc.py:108); final != 0: p = PM (rmhmc.py:110)
+__global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, double eps, int final) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1 || lane >= D) return;
+  const size_t o = (size_t)c * DP + lane;
+  const double h = ch.tau[c] * eps * 0.5;
+  const double pm = ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * ch.q[o]);
+  if (final) ch.p[o] = pm;
+  else ch.PM[o] = pm;
+}
+
+// explicit momentum half step at the new point (rmhmc.py:163) + step bookkeeping
+__global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, double eps, int advance) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  const size_t o = (size_t)c * DP + lane;
+  double pn = 0.0, wn = 0.0;
+  if (lane < D) {
+    const double h = ch.tau[c] * eps * 0.5;
+    pn = advance ? ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * ch.last[o]) : ch.p[o];
+    wn = ch.trj.w[o];
+    if (advance) ch.p[o] = pn;
+  }
+  const int nonfinite = !(isfinite(pn) && isfinite(wn));
+  const unsigned long long any = __ballot(nonfinite);
+  if (lane == 0) {
+    if (any) ch.status[c] |= 2;  // RMHMC_ST_NONFINITE
+    if (advance) {
+      ch.steps_left[c] -= 1;
+      ch.steps_done[c] += 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// transition control (rmhmc.py:47-48,59-61,80-93 and :166-191)
+// ---------------------------------------------------------------------------------------------
+struct IterParams {
+  unsigned flags;
+  int L;                  // NumOfLeapFrogSteps
+  unsigned long long seed;
+  long long chain_offset;
+  long long iter_limit;   // chains stop starting transitions at this iteration count
+  long long burn_in;
+  long long S;            // rows per chain in samples
+  double* samples;        // [n][S][D] (unpadded) or nullptr
+  const double *z_in, *ulen_in, *gdir_in, *uacc_in;  // explicit randomness (unit API) or nullptr
+  int* done_count;
+};
+
+__device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, int D, int DP, int lane) {
+  const size_t o = (size_t)c * DP;
+  if (lane < D) {
+    dst.w[o + lane] = src.w[o + lane];
+    dst.grad[o + lane] = src.grad[o + lane];
+    dst.tr[o + lane] = src.tr[o + lane];
+  }
+  const size_t m = (size_t)c * DP * DP;
+  for (int i = 0; i < D; ++i)
+    if (lane < D) {
+      dst.L[m + i * DP + lane] = src.L[m + i * DP + lane];
+      dst.Ginv[m + i * DP + lane] = src.Ginv[m + i * DP + lane];
+    }
+  if (lane == 0) {
+    dst.ljl[c] = src.ljl[c];
+    dst.hld[c] = src.hld[c];
+  }
+}
+
+// 0.5 * p' Ginv p for the chain's vector held one element per lane
+__device__ __forceinline__ double half_quadform(const double* __restrict__ Gi, int D, int DP, int lane, double pl) {
+  double y = 0.0;
+  for (int j = 0; j < D; ++j) {
+    const double pj = __shfl(pl, j, 64);
+    if (lane < D) y = fma(Gi[j * DP + lane], pj, y);
+  }
+  return 0.5 * wave_sum((lane < D) ? y * pl : 0.0);
+}
+
+__global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, IterParams ip) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 0) return;
+  const long long it = ch.iter[c];
+  if (it >= ip.iter_limit) return;
+  // trajectory starts from the cached record of the current point (wNew = w.copy(), rmhmc.py:47)
+  copy_rec(ch.trj, ch.cur, c, D, DP, lane);
+  // draws: z ~ randn(1,D), u_len ~ rand(), g_dir ~ randn()   (rmhmc.py:80,89,90)
+  double z = 0.0, u_len, g_dir;
+  if (ip.z_in) {
+    z = (lane < D) ? ip.z_in[(size_t)c * D + lane] : 0.0;
+    u_len = ip.ulen_in[c];
+    g_dir = ip.gdir_in[c];
+  } else {
+    const unsigned long long gid = (unsigned long long)(ip.chain_offset + c);
+    double U0, U1;
+    rng_block(ip.seed, gid, (uint32_t)it, (uint32_t)(lane >> 1), U0, U1);
+    const double R = sqrt(-2.0 * log(U0));
+    double sn, cs;
+    sincos(RM_PI2 * U1, &sn, &cs);
+    z = (lane < D) ? ((lane & 1) ? R * sn : R * cs) : 0.0;
+    double Ua;
+    rng_block(ip.seed, gid, (uint32_t)it, 0x40000000u, u_len, Ua);
+    rng_block(ip.seed, gid, (uint32_t)it, 0x40000001u, U0, U1);
+    g_dir = sqrt(-2.0 * log(U0)) * cos(RM_PI2 * U1);
+  }
+  // momentum p = L' z (reference, rmhmc.py:60,80) or L z (corrected)
+  const double* __restrict__ Lc = ch.cur.L + (size_t)c * DP * DP;
+  double p = 0.0;
+  if (ip.flags & 1u) {
+    for (int i = 0; i < D; ++i) {
+      const double zi = __shfl(z, i, 64);
+      if (lane <= i) p = fma(Lc[i * DP + lane], zi, p);
+    }
+  } else {
+    for (int j = 0; j < D; ++j) {
+      const double zj = __shfl(z, j, 64);
+      if (lane >= j && lane < D) p = fma(Lc[lane * DP + j], zj, p);
+    }
+  }
+  if (lane >= D) p = 0.0;
+  int st = 0;
+  if (ip.flags & 2u) {  // momentum guard, rmhmc.py:81-85
+    const double np_ = sqrt(wave_sum(p * p));
+    if (np_ > 100.0) { p /= np_ * 25.0; st = 4; }
+  }
+  const double quad = half_quadform(ch.cur.Ginv + (size_t)c * DP * DP, D, DP, lane, p);
+  if (lane < D) {
+    ch.p[(size_t)c * DP + lane] = p;
+    ch.p0[(size_t)c * DP + lane] = p;
+  }
+  if (lane == 0) {
+    const int ns = (int)ceil(u_len * (double)ip.L);  // rmhmc.py:89
+    ch.steps_left[c] = ns;
+    ch.nsteps_last[c] = ns;
+    ch.tau[c] = (g_dir > 0.5) ? 1.0 : -1.0;           // rmhmc.py:90-93
+    ch.Hcur[c] = -ch.cur.ljl[c] + ch.cur.hld[c] + quad;  // rmhmc.py:175-176
+    ch.status[c] = st;
+    ch.phase[c] = (ns > 0) ? 1 : 2;                   // 2: trajectory of zero steps, finish at once
+  }
+}
+
+__global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterParams ip) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int ph = ch.phase[c];
+  if (!(ph == 2 || (ph == 1 && ch.steps_left[c] == 0))) return;
+  const long long it = ch.iter[c];
+  const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
+  const double quad = half_quadform(ch.trj.Ginv + (size_t)c * DP * DP, D, DP, lane, pl);
+  const double Hp = -ch.trj.ljl[c] + ch.trj.hld[c] + quad;  // rmhmc.py:171-172
+  const double ratio = -Hp + ch.Hcur[c];                     // rmhmc.py:179
+  double u_acc;
+  if (ip.z_in) {
+    u_acc = ip.uacc_in[c];
+  } else {
+    double U0;
+    rng_block(ip.seed, (unsigned long long)(ip.chain_offset + c), (uint32_t)it, 0x40000000u, U0, u_acc);
+  }
+  const bool accept = (ratio > 0.0) || (ratio > log(u_acc));  // rmhmc.py:181
+  if (accept) copy_rec(ch.cur, ch.trj, c, D, DP, lane);
+  __syncthreads();
+  if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S && lane < D)
+    ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + lane] = ch.cur.w[(size_t)c * DP + lane];
+  if (lane == 0) {
+    ch.Hprop[c] = Hp;
+    if (accept) ch.accepted[c] += 1;
+    ch.iter[c] = it + 1;
+    ch.phase[c] = 0;
+    if (it + 1 == ip.iter_limit && ip.done_count) atomicAdd(ip.done_count, 1);
+  }
+}
+
+// trj -> cur for every chain (used after the initial point evaluation)
+__global__ __launch_bounds__(64) void k_commit_all(int D, int DP, Chains ch) {
+  copy_rec(ch.cur, ch.trj, blockIdx.x, D, DP, threadIdx.x);
+}
+
+// generic fills
+__global__ void k_fill_int(int* p, int v, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_fill_ll(long long* p, long long v, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// phase[c] = (nsteps[c] > 0) for the unit leapfrog API
+__global__ void k_set_leapfrog(int n, const int* __restrict__ nsteps, const int* __restrict__ dir, Chains ch) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  ch.steps_left[c] = nsteps[c];
+  ch.tau[c] = (double)dir[c];
+  ch.phase[c] = nsteps[c] > 0 ? 1 : 3;  // 3 = parked
+}
+// after each unit leapfrog step: chains that exhausted their steps are parked
+__global__ void k_park_finished(int n, Chains ch) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  if (ch.phase[c] == 1 && ch.steps_left[c] <= 0) ch.phase[c] = 3;
+}

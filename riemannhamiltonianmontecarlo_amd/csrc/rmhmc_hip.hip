@@ -1,0 +1,611 @@
+// rmhmc_hip.hip — host side of librmhmc_hip.so: the C-ABI of include/rmhmc.h on top of the gfx950
+// kernels in kernels.hip.h.  No CPU fallback: every entry point needs a HIP device.
+//
+// Scheduling: the generalised leapfrog of rmhmc.py:96-163 is a fixed sequence of
+// kernels, each over all chains; chains are independent, so transitions are started and finished
+// asynchronously (k_iter_begin / k_iter_end act only on chains whose trajectory ended) and every
+// chain executes one leapfrog step per "global step" whatever its RandomStep.
+#include "../../include/rmhmc.h"
+#include "kernels.hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+char g_err[512] = "";
+
+struct EvPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct rmhmc_ctx {
+  int device = 0;
+  int64_t M = 0, n = 0;
+  int D = 0, DP = 0, NB = 0, Mp = 0, nblk = 0;
+  uint32_t flags = 0;
+  double alpha = 100.0;
+  hipStream_t stream = nullptr;
+  DevData dd{};
+  Chains ch{};
+  std::vector<void*> allocs;
+  bool have_data = false, chains_ready = false;
+  // sampler parameters of the stateful API
+  int L = 6, K = 4;
+  double eps = 0.5;
+  uint64_t seed = 0;
+  int64_t chain_offset = 0;
+  // unit-API staging (device)
+  double *d_z = nullptr, *d_ulen = nullptr, *d_gdir = nullptr, *d_uacc = nullptr, *d_tmpD = nullptr;
+  int *d_nsteps = nullptr, *d_dir = nullptr, *d_done = nullptr;
+  long long* d_steps0 = nullptr;
+  // timing
+  bool timing = false;
+  std::map<std::string, std::vector<EvPair>> events;
+  std::vector<EvPair> pool;
+  char err[512] = "";
+};
+
+namespace {
+
+int fail(rmhmc_ctx* ctx, int code, const std::string& msg) {
+  snprintf(ctx ? ctx->err : g_err, 512, "%s", msg.c_str());
+  return code;
+}
+
+#define HIPCK(call)                                                                                        \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return fail(ctx, RMHMC_ERR_RUNTIME, std::string(hipGetErrorString(e_)) + " in " #call " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+template <typename T>
+int dalloc(rmhmc_ctx* ctx, T** p, size_t count) {
+  void* q = nullptr;
+  size_t bytes = (count ? count : 1) * sizeof(T);
+  HIPCK(hipMalloc(&q, bytes));
+  HIPCK(hipMemsetAsync(q, 0, bytes, ctx->stream));
+  ctx->allocs.push_back(q);
+  *p = (T*)q;
+  return RMHMC_OK;
+}
+
+struct Timed {
+  rmhmc_ctx* ctx;
+  EvPair ev{};
+  bool on;
+  Timed(rmhmc_ctx* c, const char* name) : ctx(c), on(c->timing) {
+    if (!on) return;
+    if (!ctx->pool.empty()) { ev = ctx->pool.back(); ctx->pool.pop_back(); }
+    else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+    (void)hipEventRecord(ev.a, ctx->stream);
+    ctx->events[name].push_back(ev);
+  }
+  ~Timed() { if (on) (void)hipEventRecord(ev.b, ctx->stream); }
+};
+
+// ---- launch helpers -----------------------------------------------------------------------------
+#define NB_SWITCH(ctx, ...)                                               \
+  switch ((ctx)->NB) {                                                    \
+    case 1: { constexpr int NB_ = 1; __VA_ARGS__; } break;                \
+    case 2: { constexpr int NB_ = 2; __VA_ARGS__; } break;                \
+    case 3: { constexpr int NB_ = 3; __VA_ARGS__; } break;                \
+    default: { constexpr int NB_ = 4; __VA_ARGS__; } break;               \
+  }
+
+int cpg_for(const rmhmc_ctx* ctx) {
+  // chains per row-pass wave: amortise the 64-row register tile over up to 64 chains while keeping
+  // >= ~4096 waves in flight
+  long long waves1 = (long long)ctx->nblk * ctx->n;
+  long long cpg = waves1 / 4096;
+  if (cpg < 1) cpg = 1;
+  if (cpg > 64) cpg = 64;
+  return (int)cpg;
+}
+
+template <int MODE>
+void launch_rowpass(rmhmc_ctx* ctx, const double* w, const double* u, double* out0, double* out1) {
+  Timed t(ctx, "rowpass");
+  const int cpg = cpg_for(ctx);
+  dim3 grid(ctx->nblk, (unsigned)((ctx->n + cpg - 1) / cpg));
+  NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<16 * NB_, MODE>), grid, dim3(64), 0, ctx->stream, ctx->dd, (int)ctx->n, cpg,
+                                     ctx->ch.phase, w, u, out0, out1, ctx->ch.ljl_part));
+}
+
+template <bool GRAD>
+void launch_assemble(rmhmc_ctx* ctx, const double* v, const double* r, const double* w) {
+  Timed t(ctx, "assemble");
+  dim3 grid((unsigned)((ctx->n + 3) / 4));
+  NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_, GRAD>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n,
+                                     ctx->ch.phase, v, r, w, ctx->ch.Gq, ctx->ch.trj.grad));
+}
+
+void launch_xtr(rmhmc_ctx* ctx, const double* r, double* out) {
+  Timed t(ctx, "xtr");
+  dim3 grid((unsigned)((ctx->n + 3) / 4));
+  NB_SWITCH(ctx, hipLaunchKernelGGL((k_xtr<NB_>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->ch.phase, r, out));
+}
+
+void launch_leverage(rmhmc_ctx* ctx) {
+  Timed t(ctx, "leverage");
+  dim3 grid((unsigned)((ctx->n + 3) / 4));
+  NB_SWITCH(ctx, hipLaunchKernelGGL((k_leverage<NB_>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->ch.phase,
+                                     ctx->ch.trj.Ginv, ctx->ch.rv1, ctx->ch.rv0, ctx->ch.trj.tr, ctx->ch.last));
+}
+
+#define SMALL(ctx, name, kern, ...)                                                               \
+  do {                                                                                            \
+    Timed t_(ctx, name);                                                                          \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ctx)->n), dim3(64), 0, (ctx)->stream, __VA_ARGS__);  \
+  } while (0)
+
+// Evaluate the point record at trj.w for every chain in phase 1 (rmhmc.py:134-161 minus the momentum
+// update): v, r, log-joint partials -> G and gradient on the matrix cores -> factor / inverse /
+// u = G^-1 p -> c, c(x.u)^2 -> leverage pass -> trace and quadratic terms.
+void launch_eval_point(rmhmc_ctx* ctx) {
+  Chains& ch = ctx->ch;
+  launch_rowpass<RP_F>(ctx, ch.trj.w, nullptr, ch.rv0, ch.rv1);
+  launch_assemble<true>(ctx, ch.rv0, ch.rv1, ch.trj.w);
+  SMALL(ctx, "factor", k_factor_full, ctx->dd, ch);
+  launch_rowpass<RP_S>(ctx, ch.trj.w, ch.uq, ch.rv0, ch.rv1);
+  launch_leverage(ctx);
+}
+
+// One generalised leapfrog step for every chain in phase 1 (rmhmc.py:96-163).
+void launch_step(rmhmc_ctx* ctx) {
+  Chains& ch = ctx->ch;
+  const int D = ctx->D, DP = ctx->DP, K = ctx->K;
+  const double eps = ctx->eps;
+  // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
+  for (int it = 0; it < K; ++it) {
+    SMALL(ctx, "small", k_ginv_matvec, D, DP, ch, it == 0 ? ch.p : ch.PM);
+    launch_rowpass<RP_S>(ctx, ch.trj.w, ch.uq, ch.rv0, ch.rv1);
+    launch_xtr(ctx, ch.rv0, ch.q);
+    SMALL(ctx, "small", k_mom_update, D, DP, ch, eps, it == K - 1 ? 1 : 0);
+  }
+  // implicit position step: K fixed-point iterations (rmhmc.py:113-123); the first one re-uses the
+  // stored factor of G(w)
+  SMALL(ctx, "factor", k_pos_first, D, DP, ch, eps);
+  for (int it = 1; it < K; ++it) {
+    launch_rowpass<RP_V>(ctx, ch.wq, nullptr, ch.rv0, nullptr);
+    launch_assemble<false>(ctx, ch.rv0, nullptr, nullptr);
+    SMALL(ctx, "factor", k_factor_solve, D, DP, ch, eps);
+  }
+  SMALL(ctx, "small", k_pos_final, D, DP, ch, (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0);
+  // explicit momentum half step at the new point (rmhmc.py:134-163)
+  launch_eval_point(ctx);
+  SMALL(ctx, "small", k_mom_final, D, DP, ch, eps, 1);
+}
+
+IterParams iter_params(rmhmc_ctx* ctx, long long limit, long long burn_in, long long S, double* samples, bool explicit_rng) {
+  IterParams ip{};
+  ip.flags = ctx->flags;
+  ip.L = ctx->L;
+  ip.seed = ctx->seed;
+  ip.chain_offset = ctx->chain_offset;
+  ip.iter_limit = limit;
+  ip.burn_in = burn_in;
+  ip.S = S;
+  ip.samples = samples;
+  if (explicit_rng) { ip.z_in = ctx->d_z; ip.ulen_in = ctx->d_ulen; ip.gdir_in = ctx->d_gdir; ip.uacc_in = ctx->d_uacc; }
+  ip.done_count = ctx->d_done;
+  return ip;
+}
+
+void launch_global_step(rmhmc_ctx* ctx, const IterParams& ip) {
+  SMALL(ctx, "small", k_iter_begin, ctx->D, ctx->DP, ctx->ch, ip);
+  launch_step(ctx);
+  SMALL(ctx, "small", k_iter_end, ctx->D, ctx->DP, ctx->ch, ip);
+}
+
+void fill_int(rmhmc_ctx* ctx, int* p, int v, size_t n) {
+  hipLaunchKernelGGL(k_fill_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, v, n);
+}
+void fill_ll(rmhmc_ctx* ctx, long long* p, long long v, size_t n) {
+  hipLaunchKernelGGL(k_fill_ll, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, v, n);
+}
+
+// host [n][D] -> device [n][DP] (padding stays zero) and back
+int upload_vec(rmhmc_ctx* ctx, double* dst, const double* src) {
+  HIPCK(hipMemcpy2DAsync(dst, ctx->DP * sizeof(double), src, ctx->D * sizeof(double), ctx->D * sizeof(double), ctx->n,
+                         hipMemcpyHostToDevice, ctx->stream));
+  return RMHMC_OK;
+}
+int download_vec(rmhmc_ctx* ctx, double* dst, const double* src) {
+  HIPCK(hipMemcpy2DAsync(dst, ctx->D * sizeof(double), src, ctx->DP * sizeof(double), ctx->D * sizeof(double), ctx->n,
+                         hipMemcpyDeviceToHost, ctx->stream));
+  return RMHMC_OK;
+}
+template <typename T>
+int download(rmhmc_ctx* ctx, T* dst, const T* src, size_t count) {
+  HIPCK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  return RMHMC_OK;
+}
+template <typename T>
+int upload(rmhmc_ctx* ctx, T* dst, const T* src, size_t count) {
+  HIPCK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return RMHMC_OK;
+}
+
+int sync(rmhmc_ctx* ctx) {
+  HIPCK(hipStreamSynchronize(ctx->stream));
+  HIPCK(hipGetLastError());
+  return RMHMC_OK;
+}
+
+#define RC(x) do { int rc_ = (x); if (rc_ != RMHMC_OK) return rc_; } while (0)
+#define NEED_DATA(ctx)                                                              \
+  do {                                                                              \
+    if (!(ctx)) return fail(nullptr, RMHMC_ERR_INVALID, "null context");            \
+    if (!(ctx)->have_data) return fail(ctx, RMHMC_ERR_INVALID, "rmhmc_set_data has not been called"); \
+    HIPCK(hipSetDevice((ctx)->device));                                             \
+  } while (0)
+
+// upload w into trj.w, zero (or upload) p, mark every chain active, evaluate the record
+int eval_at(rmhmc_ctx* ctx, const double* w, const double* p) {
+  Chains& ch = ctx->ch;
+  RC(upload_vec(ctx, ch.trj.w, w));
+  if (p) RC(upload_vec(ctx, ch.p, p));
+  else HIPCK(hipMemsetAsync(ch.p, 0, sizeof(double) * ctx->n * ctx->DP, ctx->stream));
+  fill_int(ctx, ch.phase, 1, ctx->n);
+  fill_int(ctx, ch.status, 0, ctx->n);
+  launch_eval_point(ctx);
+  return RMHMC_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+const char* rmhmc_version(void) { return "rmhmc-hip 0.1 (gfx950, fp64 MFMA)"; }
+const char* rmhmc_last_error(const rmhmc_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64_t n_chains, int32_t dtype, uint32_t flags) {
+  rmhmc_ctx* ctx = nullptr;  // for the macros: errors go to the global message
+  if (!out || M <= 0 || D <= 0 || n_chains <= 0) return fail(nullptr, RMHMC_ERR_INVALID, "rmhmc_create: bad shape");
+  if (dtype != RMHMC_F64) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: only float64 is built (the reference is float64)");
+  if (D > 64) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: D > 64 needs the tiled-Cholesky path, which is not built yet");
+  if (flags & RMHMC_FLAG_ORACLE_LITERAL) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: the literal variant exists only in the CPU oracle");
+  if (M > (int64_t)1 << 30 || n_chains > (int64_t)1 << 30) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: M or n_chains too large");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, RMHMC_ERR_NO_DEVICE, "rmhmc_create: no HIP device available (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, RMHMC_ERR_NO_DEVICE, "rmhmc_create: device ordinal out of range");
+  HIPCK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(nullptr, RMHMC_ERR_NO_DEVICE, std::string("rmhmc_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  ctx = new rmhmc_ctx();
+  ctx->device = device_id;
+  ctx->M = M; ctx->D = D; ctx->n = n_chains; ctx->flags = flags;
+  ctx->NB = (D + 15) / 16; ctx->DP = 16 * ctx->NB;
+  ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
+  int rc = RMHMC_OK;
+  auto body = [&]() -> int {
+    HIPCK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const size_t n = n_chains, DP = ctx->DP, Mp = ctx->Mp;
+    double *Xr, *Xt, *t;
+    RC(dalloc(ctx, &Xr, Mp * DP)); RC(dalloc(ctx, &Xt, DP * Mp)); RC(dalloc(ctx, &t, Mp));
+    ctx->dd.Xr = Xr; ctx->dd.Xt = Xt; ctx->dd.t = t;
+    ctx->dd.M = (int)M; ctx->dd.Mp = ctx->Mp; ctx->dd.D = D; ctx->dd.DP = ctx->DP; ctx->dd.nblk = ctx->nblk;
+    Chains& ch = ctx->ch;
+    ch.n = (int)n;
+    for (Rec* r : {&ch.cur, &ch.trj}) {
+      RC(dalloc(ctx, &r->w, n * DP)); RC(dalloc(ctx, &r->grad, n * DP)); RC(dalloc(ctx, &r->tr, n * DP));
+      RC(dalloc(ctx, &r->L, n * DP * DP)); RC(dalloc(ctx, &r->Ginv, n * DP * DP));
+      RC(dalloc(ctx, &r->ljl, n)); RC(dalloc(ctx, &r->hld, n));
+    }
+    RC(dalloc(ctx, &ch.p, n * DP)); RC(dalloc(ctx, &ch.p0, n * DP)); RC(dalloc(ctx, &ch.Hcur, n)); RC(dalloc(ctx, &ch.Hprop, n));
+    RC(dalloc(ctx, &ch.tau, n)); RC(dalloc(ctx, &ch.steps_left, n)); RC(dalloc(ctx, &ch.phase, n)); RC(dalloc(ctx, &ch.status, n));
+    RC(dalloc(ctx, &ch.nsteps_last, n)); RC(dalloc(ctx, &ch.iter, n)); RC(dalloc(ctx, &ch.accepted, n)); RC(dalloc(ctx, &ch.steps_done, n));
+    RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
+    RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
+    RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv1, n * Mp)); RC(dalloc(ctx, &ch.ljl_part, n * (size_t)ctx->nblk));
+    RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
+    RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
+    RC(dalloc(ctx, &ctx->d_tmpD, n * DP));
+    RC(sync(ctx));
+    return RMHMC_OK;
+  };
+  rc = body();
+  if (rc != RMHMC_OK) {
+    snprintf(g_err, 512, "%s", ctx->err);
+    rmhmc_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return RMHMC_OK;
+}
+
+void rmhmc_destroy(rmhmc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->events) for (auto& e : kv.second) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int rmhmc_device_info(rmhmc_ctx* ctx, char* buf, size_t len) {
+  if (!ctx || !buf) return fail(ctx, RMHMC_ERR_INVALID, "device_info: bad argument");
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, ctx->device));
+  snprintf(buf, len, "%s %s, %d CUs, %.0f MHz, %.1f GiB; M=%lld (padded %d) D=%d (padded %d, %d MFMA tiles) chains=%lld",
+           prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0,
+           (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n);
+  return RMHMC_OK;
+}
+
+int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alpha) {
+  if (!ctx || !X || !t || !(alpha > 0)) return fail(ctx, RMHMC_ERR_INVALID, "set_data: bad argument");
+  HIPCK(hipSetDevice(ctx->device));
+  const size_t M = ctx->M, D = ctx->D, DP = ctx->DP, Mp = ctx->Mp;
+  std::vector<double> xr(Mp * DP, 0.0), xt(DP * Mp, 0.0), tt(Mp, 0.0);
+  for (size_t n = 0; n < M; ++n) {
+    for (size_t d = 0; d < D; ++d) {
+      xr[n * DP + d] = X[n * D + d];
+      xt[d * Mp + n] = X[n * D + d];
+    }
+    tt[n] = t[n];
+  }
+  HIPCK(hipMemcpyAsync((void*)ctx->dd.Xr, xr.data(), xr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCK(hipMemcpyAsync((void*)ctx->dd.Xt, xt.data(), xt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCK(hipMemcpyAsync((void*)ctx->dd.t, tt.data(), tt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  RC(sync(ctx));
+  ctx->alpha = alpha;
+  ctx->dd.inv_alpha = 1.0 / alpha;
+  ctx->dd.log_prior_const = -0.5 * std::log(2.0 * M_PI * alpha);
+  ctx->have_data = true;
+  ctx->chains_ready = false;
+  return RMHMC_OK;
+}
+
+// ---- unit entry points --------------------------------------------------------------------------
+int rmhmc_log_posterior(rmhmc_ctx* ctx, const double* w, double* ljl_out) {
+  NEED_DATA(ctx);
+  if (!w || !ljl_out) return fail(ctx, RMHMC_ERR_INVALID, "log_posterior: null pointer");
+  ctx->chains_ready = false;
+  RC(eval_at(ctx, w, nullptr));
+  RC(download(ctx, ljl_out, ctx->ch.trj.ljl, ctx->n));
+  return sync(ctx);
+}
+
+int rmhmc_metric(rmhmc_ctx* ctx, const double* w, double* G_out, double* half_logdet_out, double* grad_out) {
+  NEED_DATA(ctx);
+  if (!w) return fail(ctx, RMHMC_ERR_INVALID, "metric: null pointer");
+  ctx->chains_ready = false;
+  RC(eval_at(ctx, w, nullptr));
+  if (G_out)
+    for (int64_t c = 0; c < ctx->n; ++c)  // strip the padding: [DP][DP] -> [D][D]
+      HIPCK(hipMemcpy2DAsync(G_out + c * ctx->D * ctx->D, ctx->D * 8, ctx->ch.Gq + c * ctx->DP * ctx->DP, ctx->DP * 8, ctx->D * 8, ctx->D,
+                             hipMemcpyDeviceToHost, ctx->stream));
+  if (half_logdet_out) RC(download(ctx, half_logdet_out, ctx->ch.trj.hld, ctx->n));
+  if (grad_out) RC(download_vec(ctx, grad_out, ctx->ch.trj.grad));
+  return sync(ctx);
+}
+
+int rmhmc_metric_terms(rmhmc_ctx* ctx, const double* w, const double* p, double* trace_out, double* quad_out) {
+  NEED_DATA(ctx);
+  if (!w) return fail(ctx, RMHMC_ERR_INVALID, "metric_terms: null pointer");
+  ctx->chains_ready = false;
+  RC(eval_at(ctx, w, p));
+  if (trace_out) RC(download_vec(ctx, trace_out, ctx->ch.trj.tr));
+  if (quad_out && p) RC(download_vec(ctx, quad_out, ctx->ch.last));
+  return sync(ctx);
+}
+
+int rmhmc_leapfrog(rmhmc_ctx* ctx, double* w, double* p, double eps, const int32_t* dir, const int32_t* nsteps, int32_t K,
+                   double* half_logdet_out, int32_t* status_out) {
+  NEED_DATA(ctx);
+  if (!w || !p || !dir || !nsteps || K < 1) return fail(ctx, RMHMC_ERR_INVALID, "leapfrog: null pointer or K < 1");
+  ctx->chains_ready = false;
+  int maxs = 0;
+  for (int64_t c = 0; c < ctx->n; ++c) {
+    if (nsteps[c] < 0 || (dir[c] != 1 && dir[c] != -1)) return fail(ctx, RMHMC_ERR_INVALID, "leapfrog: nsteps >= 0 and dir = +-1 required");
+    if (nsteps[c] > maxs) maxs = nsteps[c];
+  }
+  ctx->eps = eps; ctx->K = K;
+  RC(eval_at(ctx, w, p));
+  RC(upload(ctx, ctx->d_nsteps, nsteps, ctx->n));
+  RC(upload(ctx, ctx->d_dir, dir, ctx->n));
+  const unsigned g = (unsigned)((ctx->n + 255) / 256);
+  hipLaunchKernelGGL(k_set_leapfrog, dim3(g), dim3(256), 0, ctx->stream, (int)ctx->n, ctx->d_nsteps, ctx->d_dir, ctx->ch);
+  for (int s = 0; s < maxs; ++s) {
+    launch_step(ctx);
+    hipLaunchKernelGGL(k_park_finished, dim3(g), dim3(256), 0, ctx->stream, (int)ctx->n, ctx->ch);
+  }
+  RC(download_vec(ctx, w, ctx->ch.trj.w));
+  RC(download_vec(ctx, p, ctx->ch.p));
+  if (half_logdet_out) RC(download(ctx, half_logdet_out, ctx->ch.trj.hld, ctx->n));
+  if (status_out) RC(download(ctx, status_out, ctx->ch.status, ctx->n));
+  return sync(ctx);
+}
+
+// shared by transition / sample / chains_init: evaluate the record at theta0 and commit it as the
+// current point of every chain
+static int init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] or NULL */) {
+  std::vector<double> th;
+  if (!theta0_host) {
+    th.assign((size_t)ctx->n * ctx->D, 1e-3);  // rmhmc.py:27
+    theta0_host = th.data();
+  }
+  RC(eval_at(ctx, theta0_host, nullptr));
+  SMALL(ctx, "small", k_commit_all, ctx->D, ctx->DP, ctx->ch);
+  fill_int(ctx, ctx->ch.phase, 0, ctx->n);
+  fill_int(ctx, ctx->ch.steps_left, 0, ctx->n);
+  fill_int(ctx, ctx->ch.status, 0, ctx->n);
+  fill_ll(ctx, ctx->ch.iter, 0, ctx->n);
+  fill_ll(ctx, ctx->ch.accepted, 0, ctx->n);
+  fill_ll(ctx, ctx->ch.steps_done, 0, ctx->n);
+  HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+  return sync(ctx);  // theta0 staging vector goes out of scope
+}
+
+int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u_len, const double* g_dir, const double* u_acc,
+                     int32_t L, double eps, int32_t K, int32_t* accepted_out, int32_t* nsteps_out, double* H_cur_out,
+                     double* H_prop_out, double* w_prop_out, double* p_prop_out, double* half_logdet_prop_out, int32_t* status_out) {
+  NEED_DATA(ctx);
+  if (!w || !z || !u_len || !g_dir || !u_acc || L < 1 || K < 1) return fail(ctx, RMHMC_ERR_INVALID, "transition: null pointer, L < 1 or K < 1");
+  ctx->chains_ready = false;
+  ctx->L = L; ctx->eps = eps; ctx->K = K;
+  RC(init_chains(ctx, w));
+  RC(upload(ctx, ctx->d_z, z, (size_t)ctx->n * ctx->D));
+  RC(upload(ctx, ctx->d_ulen, u_len, ctx->n));
+  RC(upload(ctx, ctx->d_gdir, g_dir, ctx->n));
+  RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
+  IterParams ip = iter_params(ctx, 1, 0, 0, nullptr, true);
+  SMALL(ctx, "small", k_iter_begin, ctx->D, ctx->DP, ctx->ch, ip);
+  SMALL(ctx, "small", k_iter_end, ctx->D, ctx->DP, ctx->ch, ip);  // trajectories of zero steps
+  for (int s = 0; s < L; ++s) {
+    launch_step(ctx);
+    SMALL(ctx, "small", k_iter_end, ctx->D, ctx->DP, ctx->ch, ip);
+  }
+  std::vector<long long> acc(ctx->n);
+  RC(download_vec(ctx, w, ctx->ch.cur.w));
+  RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
+  if (nsteps_out) RC(download(ctx, nsteps_out, ctx->ch.nsteps_last, ctx->n));
+  if (H_cur_out) RC(download(ctx, H_cur_out, ctx->ch.Hcur, ctx->n));
+  if (H_prop_out) RC(download(ctx, H_prop_out, ctx->ch.Hprop, ctx->n));
+  if (w_prop_out) RC(download_vec(ctx, w_prop_out, ctx->ch.trj.w));
+  if (p_prop_out) RC(download_vec(ctx, p_prop_out, ctx->ch.p));
+  if (half_logdet_prop_out) RC(download(ctx, half_logdet_prop_out, ctx->ch.trj.hld, ctx->n));
+  if (status_out) RC(download(ctx, status_out, ctx->ch.status, ctx->n));
+  RC(sync(ctx));
+  if (accepted_out) for (int64_t c = 0; c < ctx->n; ++c) accepted_out[c] = (int32_t)acc[c];
+  return RMHMC_OK;
+}
+
+// ---- bulk entry points --------------------------------------------------------------------------
+static int run_until_done(rmhmc_ctx* ctx, const IterParams& ip, long long min_steps) {
+  // every chain needs at least min_steps more global steps; afterwards poll the done counter
+  int done = 0;
+  long long s = 0;
+  const int poll = 4;
+  for (;;) {
+    launch_global_step(ctx, ip);
+    ++s;
+    if (s >= min_steps && (s - min_steps) % poll == 0) {
+      HIPCK(hipMemcpyAsync(&done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      RC(sync(ctx));
+      if (done >= ctx->n) break;
+    }
+    if (s > min_steps * (long long)ctx->L + 1000000) return fail(ctx, RMHMC_ERR_RUNTIME, "sampler did not terminate");
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                 int64_t chain_offset, const double* theta0, double* samples_out, int64_t* accept_out, int64_t* steps_out,
+                 double* seconds_out) {
+  NEED_DATA(ctx);
+  if (!samples_out || burn_in < 0 || burn_in >= n_iter || L < 1 || K < 1)
+    return fail(ctx, RMHMC_ERR_INVALID, "sample: need samples_out, 0 <= burn_in < n_iter, L >= 1, K >= 1");
+  ctx->chains_ready = false;
+  ctx->L = L; ctx->eps = eps; ctx->K = K; ctx->seed = seed; ctx->chain_offset = chain_offset;
+  const long long S = n_iter - burn_in;
+  double* d_samples = nullptr;
+  HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
+  int rc = [&]() -> int {
+    RC(init_chains(ctx, theta0));
+    // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
+    // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
+    IterParams ipA = iter_params(ctx, burn_in + 1, burn_in, S, d_samples, false);
+    RC(run_until_done(ctx, ipA, burn_in + 1));
+    HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+    RC(sync(ctx));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_iter > burn_in + 1) {
+      IterParams ipB = iter_params(ctx, n_iter, burn_in, S, d_samples, false);
+      RC(run_until_done(ctx, ipB, n_iter - burn_in - 1));
+    }
+    RC(sync(ctx));
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (seconds_out) *seconds_out = secs;
+    HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<long long> a(ctx->n), s1(ctx->n), s0(ctx->n);
+    RC(download(ctx, a.data(), ctx->ch.accepted, ctx->n));
+    RC(download(ctx, s1.data(), ctx->ch.steps_done, ctx->n));
+    RC(download(ctx, s0.data(), ctx->d_steps0, ctx->n));
+    RC(sync(ctx));
+    for (int64_t c = 0; c < ctx->n; ++c) {
+      if (accept_out) accept_out[c] = a[c];
+      if (steps_out) steps_out[c] = s1[c] - s0[c];
+    }
+    return RMHMC_OK;
+  }();
+  (void)hipFree(d_samples);
+  return rc;
+}
+
+int rmhmc_chains_init(rmhmc_ctx* ctx, const double* theta0, uint64_t seed, int64_t chain_offset, int32_t L, double eps, int32_t K) {
+  NEED_DATA(ctx);
+  if (L < 1 || K < 1) return fail(ctx, RMHMC_ERR_INVALID, "chains_init: L >= 1 and K >= 1 required");
+  ctx->L = L; ctx->eps = eps; ctx->K = K; ctx->seed = seed; ctx->chain_offset = chain_offset;
+  RC(init_chains(ctx, theta0));
+  ctx->chains_ready = true;
+  return RMHMC_OK;
+}
+
+int rmhmc_chains_run(rmhmc_ctx* ctx, int64_t n_steps) {
+  NEED_DATA(ctx);
+  if (!ctx->chains_ready) return fail(ctx, RMHMC_ERR_INVALID, "chains_run: rmhmc_chains_init has not been called");
+  IterParams ip = iter_params(ctx, (long long)1 << 62, 0, 0, nullptr, false);
+  ip.done_count = nullptr;
+  {
+    Timed t(ctx, "total");
+    for (int64_t s = 0; s < n_steps; ++s) launch_global_step(ctx, ip);
+  }
+  return sync(ctx);
+}
+
+int rmhmc_chains_state(rmhmc_ctx* ctx, double* w_out, int64_t* iters_out, int64_t* accept_out) {
+  NEED_DATA(ctx);
+  if (!ctx->chains_ready) return fail(ctx, RMHMC_ERR_INVALID, "chains_state: rmhmc_chains_init has not been called");
+  if (w_out) RC(download_vec(ctx, w_out, ctx->ch.cur.w));
+  static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+  if (iters_out) RC(download(ctx, (long long*)iters_out, ctx->ch.iter, ctx->n));
+  if (accept_out) RC(download(ctx, (long long*)accept_out, ctx->ch.accepted, ctx->n));
+  return sync(ctx);
+}
+
+int rmhmc_kernel_time(rmhmc_ctx* ctx, const char* which, double* seconds_out, int64_t* launches_out) {
+  if (!ctx || !which) return fail(ctx, RMHMC_ERR_INVALID, "kernel_time: bad argument");
+  HIPCK(hipSetDevice(ctx->device));
+  const std::string w(which);
+  if (seconds_out) *seconds_out = 0.0;
+  if (launches_out) *launches_out = 0;
+  if (w == "enable") { ctx->timing = true; return RMHMC_OK; }
+  if (w == "disable") { ctx->timing = false; return RMHMC_OK; }
+  if (w == "reset") {
+    RC(sync(ctx));
+    for (auto& kv : ctx->events) { for (auto& e : kv.second) ctx->pool.push_back(e); kv.second.clear(); }
+    return RMHMC_OK;
+  }
+  RC(sync(ctx));
+  auto it = ctx->events.find(w);
+  if (it == ctx->events.end()) return RMHMC_OK;
+  double ms = 0.0;
+  for (auto& e : it->second) {
+    float m = 0.f;
+    HIPCK(hipEventElapsedTime(&m, e.a, e.b));
+    ms += m;
+  }
+  if (seconds_out) *seconds_out = ms * 1e-3;
+  if (launches_out) *launches_out = (int64_t)it->second.size();
+  return RMHMC_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the HIP library is dlopen-ed: one HIP runtime per process, see _capi.load_hip_library)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

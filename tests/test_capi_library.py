@@ -1,0 +1,56 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/rmhmc.h declares,
+and fails loudly (no CPU fallback) when there is no GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from riemannhamiltonianmontecarlo_amd import _capi, RMHMC
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "rmhmc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(rmhmc_[a-z_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree():
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    assert set(syms) == set(_capi.SIGNATURES), set(syms) ^ set(_capi.SIGNATURES)
+
+
+def test_hip_library_exports_every_declared_symbol(hip):
+    import ctypes
+    lib = ctypes.CDLL(hip.path)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), s
+    assert "gfx950" in hip.version()
+
+
+def test_oracle_exports_the_same_abi(oracle):
+    import ctypes
+    lib = ctypes.CDLL(oracle.path)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), s
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(hip):
+    with pytest.raises(_capi.RmhmcError) as e:
+        hip.context(10, 3, 1)
+    assert e.value.code == -2 and "no HIP device" in str(e.value)
+    X = np.random.RandomState(0).randn(10, 3); t = (X[:, 0] > 0).astype(float)
+    with pytest.raises(_capi.RmhmcError):
+        RMHMC(X, t, NumOfIterations=4, BurnIn=1, verbose=False)
+
+
+def test_shim_argument_checks():
+    X = np.zeros((5, 2)); t = np.zeros(5)
+    with pytest.raises(ValueError):
+        RMHMC(X, t, NumOfIterations=10, BurnIn=10)
+    with pytest.raises(ValueError):
+        RMHMC(X, np.zeros(4))
