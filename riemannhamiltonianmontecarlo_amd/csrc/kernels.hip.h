@@ -213,8 +213,12 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
         const int col = NB * ci + J;
         double val = acc[t][r];
         if (row == col) val += dd.inv_alpha;
-        G[row * DP + col] = val;
-        if (I != J) G[col * DP + row] = val;
+        // diagonal tiles hold both triangles (rounded differently): keep the lower one and mirror it,
+        // so that G is exactly symmetric
+        if (I != J || row >= col) {
+          G[row * DP + col] = val;
+          G[col * DP + row] = val;
+        }
       }
       ++t;
     }
