@@ -56,8 +56,9 @@ def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0):
     if not os.path.exists(ge.ORACLE_LIB):
         return None
     oracle = _capi.RmhmcLib(ge.ORACLE_LIB)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, int(os.environ.get("RMHMC_CPU_THREADS", "16")))  # one GPU's CPU share on the box is 16 cores
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     M, D = XX.shape
     n = cores
     with oracle.context(M, D, n, flags=flags) as ctx:
