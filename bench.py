@@ -131,7 +131,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kt = {k: ctx.kernel_time(k) for k in ("assemble", "leverage", "rowpass", "xtr", "factor", "small", "total")}
+    kt = {k: ctx.kernel_time(k) for k in ("assemble", "leverage", "rowpass", "mompass", "factor", "small", "total")}
     ctx.kernel_time("disable")
     w_end, iters, acc = ctx.chains_state()
     finite = bool(np.isfinite(w_end).all())

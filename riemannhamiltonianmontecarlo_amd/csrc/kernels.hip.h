@@ -38,7 +38,7 @@ struct Chains {
   int *steps_left, *phase, *status, *nsteps_last;
   long long *iter, *accepted, *steps_done;
   // scratch
-  double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv1, *ljl_part;
+  double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv1, *rv2, *ljl_part, *qpart;
   int n;
 };
 
@@ -93,16 +93,15 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 // chains; the chain's vectors are wave-uniform (scalar loads).  Replaces the f/p/v blocks of
 // rmhmc.py:51-53,99-100,116-118,134-136,166-168 and the c = v(1-2p) factor of :67,:148.
 //   RP_V : out0 = v_n = p(1-p),  p = 1/(1+e^-f),  f = x_n.wq                 (rmhmc.py:116-118)
-//   RP_F : out0 = v_n, out1 = t_n - e^f/(1+e^f) (rmhmc.py:140), ljl partial  (rmhmc.py:167-168)
-//   RP_S : out0 = c_n (x_n.uq)^2, out1 = c_n, with c from f = x_n.wq        (rmhmc.py:104-107)
+//   RP_F : out0 = v_n, out1 = t_n - e^f/(1+e^f) (rmhmc.py:140), out2 = c_n, ljl partial (rmhmc.py:167-168)
 // ---------------------------------------------------------------------------------------------
-enum { RP_V = 0, RP_F = 1, RP_S = 2 };
+enum { RP_V = 0, RP_F = 1 };
 
 template <int DP, int MODE>
 __global__ __launch_bounds__(64) void k_rowpass(DevData dd, int n_chains, int cpg, const int* __restrict__ phase,
-                                                const double* __restrict__ wq, const double* __restrict__ uq,
+                                                const double* __restrict__ wq,
                                                 double* __restrict__ out0, double* __restrict__ out1,
-                                                double* __restrict__ ljl_part) {
+                                                double* __restrict__ out2, double* __restrict__ ljl_part) {
   const int lane = threadIdx.x;
   const int blk = blockIdx.x;
   const size_t n = (size_t)blk * 64 + lane;
@@ -125,21 +124,14 @@ __global__ __launch_bounds__(64) void k_rowpass(DevData dd, int n_chains, int cp
     const size_t o = (size_t)c * dd.Mp + n;
     if (MODE == RP_V) {
       out0[o] = v;
-    } else if (MODE == RP_F) {
+    } else {
       const double ef = exp(f);
       out0[o] = v;
       out1[o] = tn - ef / (1.0 + ef);
+      out2[o] = v * (1.0 - 2.0 * p);
       double term = valid ? (f * tn - log(1.0 + ef)) : 0.0;
       term = wave_sum(term);
       if (lane == 0) ljl_part[(size_t)c * dd.nblk + blk] = term;
-    } else {
-      const double* __restrict__ u = uq + (size_t)c * DP;
-      double s = 0.0;
-#pragma unroll
-      for (int d = 0; d < DP; ++d) s = fma(x[d], u[d], s);
-      const double cn = v * (1.0 - 2.0 * p);
-      out0[o] = cn * s * s;
-      out1[o] = cn;
     }
   }
 }
@@ -233,42 +225,81 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3  q = X' r  for one row vector per chain (the contraction u' dG_d u = sum_n c_n (x_n.u)^2 x_nd
-// of rmhmc.py:104-107 once r = c (x.u)^2 is known).  One chain per wavefront, same lane layout as
-// k_assemble (4 rows x 16 column groups per step).
+// K3b  fused quadratic-term pass on the matrix cores, 16 chains per wavefront:
+//        q_c[d] = sum_n c_n(w_c) (x_n.u_c)^2 x_nd  = u' dG/dw_d u      (rmhmc.py:104-107,158-161)
+// as three small GEMMs per 16 data rows:  F = X W, S = X U  (16 rows x 16 chains, K = D) and
+// Q += X' R with R = c(F) S^2.  The accumulator layout of F/S (register r <-> data row (lane>>4)+4r,
+// column lane&15 = chain) is exactly the B-operand layout of the third product for the 4-row chunk r,
+// so R feeds the matrix core without any lane movement.  X is read once per 16 chains.
+// Rows are split over blockIdx.y; partial sums go to qpart[split][chain][d] (summed, in fixed order,
+// by the momentum-update kernel: deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(256) void k_xtr(DevData dd, int n_chains, const int* __restrict__ phase,
-                                             const double* __restrict__ rrow, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int nsplit, const double* __restrict__ wq,
+                                                 const double* __restrict__ uq, double* __restrict__ qpart) {
   constexpr int DP = 16 * NB;
+  constexpr int KK = DP / 4;
   const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= n_chains) return;
-  if (phase[c] != 1) return;
+  const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  if (c0 >= n_chains) return;
+  const int split = blockIdx.y;
   const int rr = lane >> 4, ci = lane & 15;
-  const double* __restrict__ xp = dd.Xr + (size_t)rr * DP + NB * ci;
-  const double* __restrict__ rp = rrow + (size_t)c * dd.Mp + rr;
-  double acc[NB];
+  const int cj = min(c0 + ci, n_chains - 1);
+  double Wb[KK], Ub[KK];
 #pragma unroll
-  for (int I = 0; I < NB; ++I) acc[I] = 0.0;
-#pragma unroll 8
-  for (int n0 = 0; n0 < dd.Mp; n0 += 4) {
-    const double rv = rp[n0];
-#pragma unroll
-    for (int I = 0; I < NB; ++I) acc[I] = fma(rv, xp[(size_t)n0 * DP + I], acc[I]);
+  for (int kk = 0; kk < KK; ++kk) {
+    Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
+    Ub[kk] = uq[(size_t)cj * DP + 4 * kk + rr];
   }
+  const int nb16 = dd.Mp / 16;
+  const int per = (nb16 + nsplit - 1) / nsplit;
+  const int b0 = split * per, b1 = min(nb16, b0 + per);
+  d4 Q[NB];
 #pragma unroll
-  for (int I = 0; I < NB; ++I) {
-    const double g = col4_sum(acc[I]);
-    const int d = NB * ci + I;
-    if (rr == 0 && d < dd.D) out[(size_t)c * DP + d] = g;
+  for (int I = 0; I < NB; ++I) Q[I] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + ci;     // A of F,S: X[n0+ci][4kk+rr]
+  const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;   // A of Q  : X[n0+4r+rr][NB*ci+I]
+  for (int b = b0; b < b1; ++b) {
+    const int n0 = b * 16;
+    double A[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + n0];
+    double xb[4][NB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + 4 * r) * DP + I];
+    d4 F = (d4){0.0, 0.0, 0.0, 0.0}, S = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Ub[kk], S, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double em = exp(-F[r]);
+      const double p = 1.0 / (1.0 + em);
+      const double cn = p * (1.0 - p) * (1.0 - 2.0 * p);
+      const double R = cn * S[r] * S[r];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], R, Q[I], 0, 0, 0);
+    }
+  }
+  if (c0 + ci < n_chains) {
+    double* __restrict__ out = qpart + ((size_t)split * n_chains + c0 + ci) * DP;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = NB * (rr + 4 * r) + I;
+        if (d < dd.D) out[d] = Q[I][r];
+      }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // K4  leverage pass on the matrix cores: h_n = x_n' G^-1 x_n for every data row, then
 //       tr_d   = sum_n c_n h_n x_nd          (= tr(G^-1 dG/dw_d),      rmhmc.py:67-77,148-156)
-//       last_d = sum_n cs2_n x_nd            (= u' dG/dw_d u,          rmhmc.py:158-161)
 // Y = X * Ghat with Ghat the block-upper-triangular fold of the symmetric G^-1 (off-diagonal
 // blocks doubled) so only NB(NB+1)/2 blocks are multiplied; h = rowsum(Y .* X).
 // Blocks use the same column permutation as k_assemble (block I = columns NB*m + I).
@@ -279,8 +310,7 @@ __global__ __launch_bounds__(256) void k_xtr(DevData dd, int n_chains, const int
 template <int NB>
 __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, const int* __restrict__ phase,
                                                   const double* __restrict__ Ginv, const double* __restrict__ crow,
-                                                  const double* __restrict__ cs2row, double* __restrict__ tr,
-                                                  double* __restrict__ last) {
+                                                  double* __restrict__ tr) {
   constexpr int DP = 16 * NB;
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -302,10 +332,9 @@ __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, cons
   const double* __restrict__ xa_p = dd.Xr + (size_t)ci * DP + NB * rr;       // A layout: row n0+ci, col NB*(4s+rr)+I
   const double* __restrict__ xc_p = dd.Xr + (size_t)rr * DP + NB * ci;       // C layout: row n0+rr+4r, col NB*ci+J
   const double* __restrict__ cp = crow + (size_t)c * dd.Mp + rr;
-  const double* __restrict__ sp = cs2row + (size_t)c * dd.Mp + rr;
-  double tracc[NB], lacc[NB];
+  double tracc[NB];
 #pragma unroll
-  for (int J = 0; J < NB; ++J) { tracc[J] = 0.0; lacc[J] = 0.0; }
+  for (int J = 0; J < NB; ++J) tracc[J] = 0.0;
 
   for (int n0 = 0; n0 < dd.Mp; n0 += 16) {
     double A[4][NB], Xc[4][NB];
@@ -333,23 +362,15 @@ __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, cons
       for (int J = 0; J < NB; ++J) hp = fma(Y[J][r], Xc[r][J], hp);
       const double h = row16_sum(hp);
       const double ch = cp[n0 + 4 * r] * h;
-      const double cs = sp[n0 + 4 * r];
 #pragma unroll
-      for (int J = 0; J < NB; ++J) {
-        tracc[J] = fma(ch, Xc[r][J], tracc[J]);
-        lacc[J] = fma(cs, Xc[r][J], lacc[J]);
-      }
+      for (int J = 0; J < NB; ++J) tracc[J] = fma(ch, Xc[r][J], tracc[J]);
     }
   }
 #pragma unroll
   for (int J = 0; J < NB; ++J) {
     const double a = col4_sum(tracc[J]);
-    const double b = col4_sum(lacc[J]);
     const int d = NB * ci + J;
-    if (rr == 0 && d < dd.D) {
-      tr[(size_t)c * DP + d] = a;
-      last[(size_t)c * DP + d] = b;
-    }
+    if (rr == 0 && d < dd.D) tr[(size_t)c * DP + d] = a;
   }
 }
 
@@ -511,25 +532,30 @@ __global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, co
 }
 
 // PM = p + tau*eps/2 * (grad - tr/2 + q/2)   (rmhmc.py:108); final != 0: p = PM (rmhmc.py:110)
-__global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, double eps, int final) {
+__global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, double eps, int final, int nsplit) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 1 || lane >= D) return;
   const size_t o = (size_t)c * DP + lane;
   const double h = ch.tau[c] * eps * 0.5;
-  const double pm = ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * ch.q[o]);
+  double q = 0.0;
+  for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + lane];
+  const double pm = ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
   if (final) ch.p[o] = pm;
   else ch.PM[o] = pm;
 }
 
 // explicit momentum half step at the new point (rmhmc.py:163) + step bookkeeping
-__global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, double eps, int advance) {
+__global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, double eps, int advance, int nsplit) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 1) return;
   const size_t o = (size_t)c * DP + lane;
   double pn = 0.0, wn = 0.0;
   if (lane < D) {
     const double h = ch.tau[c] * eps * 0.5;
-    pn = advance ? ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * ch.last[o]) : ch.p[o];
+    double q = 0.0;
+    for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + lane];
+    ch.last[o] = q;
+    pn = advance ? ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q) : ch.p[o];
     wn = ch.trj.w[o];
     if (advance) ch.p[o] = pn;
   }

@@ -27,7 +27,7 @@ struct EvPair { hipEvent_t a, b; };
 struct rmhmc_ctx {
   int device = 0;
   int64_t M = 0, n = 0;
-  int D = 0, DP = 0, NB = 0, Mp = 0, nblk = 0;
+  int D = 0, DP = 0, NB = 0, Mp = 0, nblk = 0, nsplit = 1;
   uint32_t flags = 0;
   double alpha = 100.0;
   hipStream_t stream = nullptr;
@@ -110,12 +110,12 @@ int cpg_for(const rmhmc_ctx* ctx) {
 }
 
 template <int MODE>
-void launch_rowpass(rmhmc_ctx* ctx, const double* w, const double* u, double* out0, double* out1) {
+void launch_rowpass(rmhmc_ctx* ctx, const double* w, double* out0, double* out1 = nullptr, double* out2 = nullptr) {
   Timed t(ctx, "rowpass");
   const int cpg = cpg_for(ctx);
   dim3 grid(ctx->nblk, (unsigned)((ctx->n + cpg - 1) / cpg));
   NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<16 * NB_, MODE>), grid, dim3(64), 0, ctx->stream, ctx->dd, (int)ctx->n, cpg,
-                                     ctx->ch.phase, w, u, out0, out1, ctx->ch.ljl_part));
+                                     ctx->ch.phase, w, out0, out1, out2, ctx->ch.ljl_part));
 }
 
 template <bool GRAD>
@@ -126,17 +126,19 @@ void launch_assemble(rmhmc_ctx* ctx, const double* v, const double* r, const dou
                                      ctx->ch.phase, v, r, w, ctx->ch.Gq, ctx->ch.trj.grad));
 }
 
-void launch_xtr(rmhmc_ctx* ctx, const double* r, double* out) {
-  Timed t(ctx, "xtr");
-  dim3 grid((unsigned)((ctx->n + 3) / 4));
-  NB_SWITCH(ctx, hipLaunchKernelGGL((k_xtr<NB_>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->ch.phase, r, out));
+// q partials of u' dG/dw_d u for every chain (u = ch.uq, w as given); summed by k_mom_update / k_mom_final
+void launch_mompass(rmhmc_ctx* ctx, const double* w) {
+  Timed t(ctx, "mompass");
+  dim3 grid((unsigned)((ctx->n + 63) / 64), ctx->nsplit);
+  NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->nsplit, w,
+                                    ctx->ch.uq, ctx->ch.qpart));
 }
 
 void launch_leverage(rmhmc_ctx* ctx) {
   Timed t(ctx, "leverage");
   dim3 grid((unsigned)((ctx->n + 3) / 4));
   NB_SWITCH(ctx, hipLaunchKernelGGL((k_leverage<NB_>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->ch.phase,
-                                     ctx->ch.trj.Ginv, ctx->ch.rv1, ctx->ch.rv0, ctx->ch.trj.tr, ctx->ch.last));
+                                     ctx->ch.trj.Ginv, ctx->ch.rv2, ctx->ch.trj.tr));
 }
 
 #define SMALL(ctx, name, kern, ...)                                                               \
@@ -148,13 +150,14 @@ void launch_leverage(rmhmc_ctx* ctx) {
 // Evaluate the point record at trj.w for every chain in phase 1 (rmhmc.py:134-161 minus the momentum
 // update): v, r, log-joint partials -> G and gradient on the matrix cores -> factor / inverse /
 // u = G^-1 p -> c, c(x.u)^2 -> leverage pass -> trace and quadratic terms.
-void launch_eval_point(rmhmc_ctx* ctx) {
+void launch_eval_point(rmhmc_ctx* ctx, bool advance) {
   Chains& ch = ctx->ch;
-  launch_rowpass<RP_F>(ctx, ch.trj.w, nullptr, ch.rv0, ch.rv1);
+  launch_rowpass<RP_F>(ctx, ch.trj.w, ch.rv0, ch.rv1, ch.rv2);
   launch_assemble<true>(ctx, ch.rv0, ch.rv1, ch.trj.w);
   SMALL(ctx, "factor", k_factor_full, ctx->dd, ch);
-  launch_rowpass<RP_S>(ctx, ch.trj.w, ch.uq, ch.rv0, ch.rv1);
+  launch_mompass(ctx, ch.trj.w);
   launch_leverage(ctx);
+  SMALL(ctx, "small", k_mom_final, ctx->D, ctx->DP, ch, ctx->eps, advance ? 1 : 0, ctx->nsplit);
 }
 
 // One generalised leapfrog step for every chain in phase 1 (rmhmc.py:96-163).
@@ -165,22 +168,20 @@ void launch_step(rmhmc_ctx* ctx) {
   // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
   for (int it = 0; it < K; ++it) {
     SMALL(ctx, "small", k_ginv_matvec, D, DP, ch, it == 0 ? ch.p : ch.PM);
-    launch_rowpass<RP_S>(ctx, ch.trj.w, ch.uq, ch.rv0, ch.rv1);
-    launch_xtr(ctx, ch.rv0, ch.q);
-    SMALL(ctx, "small", k_mom_update, D, DP, ch, eps, it == K - 1 ? 1 : 0);
+    launch_mompass(ctx, ch.trj.w);
+    SMALL(ctx, "small", k_mom_update, D, DP, ch, eps, it == K - 1 ? 1 : 0, ctx->nsplit);
   }
   // implicit position step: K fixed-point iterations (rmhmc.py:113-123); the first one re-uses the
   // stored factor of G(w)
   SMALL(ctx, "factor", k_pos_first, D, DP, ch, eps);
   for (int it = 1; it < K; ++it) {
-    launch_rowpass<RP_V>(ctx, ch.wq, nullptr, ch.rv0, nullptr);
+    launch_rowpass<RP_V>(ctx, ch.wq, ch.rv0);
     launch_assemble<false>(ctx, ch.rv0, nullptr, nullptr);
     SMALL(ctx, "factor", k_factor_solve, D, DP, ch, eps);
   }
   SMALL(ctx, "small", k_pos_final, D, DP, ch, (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0);
   // explicit momentum half step at the new point (rmhmc.py:134-163)
-  launch_eval_point(ctx);
-  SMALL(ctx, "small", k_mom_final, D, DP, ch, eps, 1);
+  launch_eval_point(ctx, true);
 }
 
 IterParams iter_params(rmhmc_ctx* ctx, long long limit, long long burn_in, long long S, double* samples, bool explicit_rng) {
@@ -255,7 +256,7 @@ int eval_at(rmhmc_ctx* ctx, const double* w, const double* p) {
   else HIPCK(hipMemsetAsync(ch.p, 0, sizeof(double) * ctx->n * ctx->DP, ctx->stream));
   fill_int(ctx, ch.phase, 1, ctx->n);
   fill_int(ctx, ch.status, 0, ctx->n);
-  launch_eval_point(ctx);
+  launch_eval_point(ctx, false);
   return RMHMC_OK;
 }
 
@@ -310,7 +311,16 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     RC(dalloc(ctx, &ch.nsteps_last, n)); RC(dalloc(ctx, &ch.iter, n)); RC(dalloc(ctx, &ch.accepted, n)); RC(dalloc(ctx, &ch.steps_done, n));
     RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
     RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
-    RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv1, n * Mp)); RC(dalloc(ctx, &ch.ljl_part, n * (size_t)ctx->nblk));
+    RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv1, n * Mp)); RC(dalloc(ctx, &ch.rv2, n * Mp));
+    RC(dalloc(ctx, &ch.ljl_part, n * (size_t)ctx->nblk));
+    {  // row splits of the fused momentum pass: aim at >= ~6000 waves of 16 chains each
+      const long long groups = (n_chains + 15) / 16, nb16 = ctx->Mp / 16;
+      long long ns = (6144 + groups - 1) / groups;
+      if (ns < 1) ns = 1;
+      if (ns > nb16) ns = nb16;
+      ctx->nsplit = (int)ns;
+    }
+    RC(dalloc(ctx, &ch.qpart, (size_t)ctx->nsplit * n * DP));
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
     RC(dalloc(ctx, &ctx->d_tmpD, n * DP));
