@@ -168,29 +168,44 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
 #pragma unroll
   for (int I = 0; I < NB; ++I) gacc[I] = 0.0;
 
-  // Mp is a multiple of 64: 4 chunks of 4 data rows per trip, loads of all four issued up front
-  for (int n1 = 0; n1 < dd.Mp; n1 += 16)
+  // Software pipeline over 16-row groups (4 MFMA k-chunks of 4 data rows): the loads of the next group are
+  // issued before the 4*NT MFMAs of the current one.  Mp is a multiple of 64, so groups come in pairs.
+  double xbA[4][NB], vA[4], rA[4], xbB[4][NB], vB[4], rB[4];
+  auto load_group = [&](double (&xb)[4][NB], double (&vv)[4], double (&rv)[4], int n1) {
 #pragma unroll
-  for (int n0 = n1; n0 < n1 + 16; n0 += 4) {
-    double xb[NB], xa[NB];
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int I = 0; I < NB; ++I) xb[I] = xp[(size_t)n0 * DP + I];
-    const double vv = vp[n0];
-#pragma unroll
-    for (int I = 0; I < NB; ++I) xa[I] = vv * xb[I];
-    if (GRAD) {
-      const double rv = rp[n0];
-#pragma unroll
-      for (int I = 0; I < NB; ++I) gacc[I] = fma(rv, xb[I], gacc[I]);
+      for (int I = 0; I < NB; ++I) xb[q][I] = xp[(size_t)(n1 + 4 * q) * DP + I];
+      vv[q] = vp[n1 + 4 * q];
+      if (GRAD) rv[q] = rp[n1 + 4 * q];
     }
-    int t = 0;
+  };
+  auto compute_group = [&](const double (&xb)[4][NB], const double (&vv)[4], const double (&rv)[4]) {
 #pragma unroll
-    for (int I = 0; I < NB; ++I)
+    for (int q = 0; q < 4; ++q) {
+      double xa[NB];
 #pragma unroll
-      for (int J = I; J < NB; ++J) {
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[I], xb[J], acc[t], 0, 0, 0);
-        ++t;
+      for (int I = 0; I < NB; ++I) xa[I] = vv[q] * xb[q][I];
+      if (GRAD) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) gacc[I] = fma(rv[q], xb[q][I], gacc[I]);
       }
+      int t = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[I], xb[q][J], acc[t], 0, 0, 0);
+          ++t;
+        }
+    }
+  };
+  load_group(xbA, vA, rA, 0);
+  for (int n1 = 0; n1 < dd.Mp; n1 += 32) {
+    load_group(xbB, vB, rB, n1 + 16);
+    compute_group(xbA, vA, rA);
+    if (n1 + 32 < dd.Mp) load_group(xbA, vA, rA, n1 + 32);
+    compute_group(xbB, vB, rB);
   }
   // epilogue: scatter the permuted tiles into the natural row-major DPxDP matrix (+ I/alpha)
   double* __restrict__ G = Gq + (size_t)c * DP * DP;
