@@ -89,50 +89,72 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1  row pass (lane = data row).  64 rows of X live in registers and are re-used for `cpg`
-// chains; the chain's vectors are wave-uniform (scalar loads).  Replaces the f/p/v blocks of
-// rmhmc.py:51-53,99-100,116-118,134-136,166-168 and the c = v(1-2p) factor of :67,:148.
-//   RP_V : out0 = v_n = p(1-p),  p = 1/(1+e^-f),  f = x_n.wq                 (rmhmc.py:116-118)
-//   RP_F : out0 = v_n, out1 = t_n - e^f/(1+e^f) (rmhmc.py:140), out2 = c_n, ljl partial (rmhmc.py:167-168)
+// K1  row pass on the matrix cores, 16 chains per wavefront: F = X W (16 data rows x 16 chains per
+// MFMA tile, K = D), then the per-(row, chain) scalars the other kernels consume.  Replaces the f/p/v
+// blocks of rmhmc.py:51-53,99-100,116-118,134-136,166-168 and the c = v(1-2p) factor of :67,:148.
+//   RP_V : out0 = v_n = p(1-p),  p = 1/(1+e^-f),  f = x_n.wq                          (rmhmc.py:116-118)
+//   RP_F : out0 = v_n, out1 = t_n - e^f/(1+e^f) (rmhmc.py:140), out2 = c_n, log-joint partial sums
+//          sum_n f t - log(1+e^f) per (chain, row split)                               (rmhmc.py:167-168)
+// The naive exp/log forms are kept on purpose: they overflow exactly where the reference does.
+// Accumulator register r of lane l holds data row (l>>4)+4r of the tile and chain l&15.
 // ---------------------------------------------------------------------------------------------
 enum { RP_V = 0, RP_F = 1 };
 
-template <int DP, int MODE>
-__global__ __launch_bounds__(64) void k_rowpass(DevData dd, int n_chains, int cpg, const int* __restrict__ phase,
-                                                const double* __restrict__ wq,
-                                                double* __restrict__ out0, double* __restrict__ out1,
-                                                double* __restrict__ out2, double* __restrict__ ljl_part) {
-  const int lane = threadIdx.x;
-  const int blk = blockIdx.x;
-  const size_t n = (size_t)blk * 64 + lane;
-  double x[DP];
+template <int NB, int MODE>
+__global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
+                                                 const double* __restrict__ wq, double* __restrict__ out0,
+                                                 double* __restrict__ out1, double* __restrict__ out2,
+                                                 double* __restrict__ ljl_part) {
+  constexpr int DP = 16 * NB;
+  constexpr int KK = DP / 4;
+  const int lane = threadIdx.x & 63;
+  const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  if (c0 >= n_chains) return;
+  const int split = blockIdx.y;
+  const int rr = lane >> 4, ci = lane & 15;
+  const int cj = min(c0 + ci, n_chains - 1);
+  const bool live = (c0 + ci < n_chains) && (phase[cj] == 1);
+  double Wb[KK];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x[d] = dd.Xt[(size_t)d * dd.Mp + n];
-  const double tn = dd.t[n];
-  const bool valid = n < (size_t)dd.M;
-  const int c0 = blockIdx.y * cpg;
-  const int c1 = min(c0 + cpg, n_chains);
-  for (int c = c0; c < c1; ++c) {
-    if (phase[c] != 1) continue;  // wave-uniform
-    const double* __restrict__ w = wq + (size_t)c * DP;
-    double f = 0.0;
+  for (int kk = 0; kk < KK; ++kk) Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
+  const int nb16 = dd.Mp / 16;
+  const int per = (nb16 + nsplit - 1) / nsplit;
+  const int b0 = split * per, b1 = min(nb16, b0 + per);
+  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + ci;  // A: X[n0+ci][4kk+rr]
+  double lj = 0.0;
+  for (int b = b0; b < b1; ++b) {
+    const int n0 = b * 16;
+    double A[KK];
 #pragma unroll
-    for (int d = 0; d < DP; ++d) f = fma(x[d], w[d], f);
-    const double em = exp(-f);
-    const double p = 1.0 / (1.0 + em);
-    const double v = p * (1.0 - p);
-    const size_t o = (size_t)c * dd.Mp + n;
-    if (MODE == RP_V) {
-      out0[o] = v;
-    } else {
-      const double ef = exp(f);
-      out0[o] = v;
-      out1[o] = tn - ef / (1.0 + ef);
-      out2[o] = v * (1.0 - 2.0 * p);
-      double term = valid ? (f * tn - log(1.0 + ef)) : 0.0;
-      term = wave_sum(term);
-      if (lane == 0) ljl_part[(size_t)c * dd.nblk + blk] = term;
+    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + n0];
+    d4 F = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + rr + 4 * r;
+      const double f = F[r];
+      const double em = exp(-f);
+      const double p = 1.0 / (1.0 + em);
+      const double v = p * (1.0 - p);
+      const size_t o = (size_t)cj * dd.Mp + n;
+      if (MODE == RP_V) {
+        if (live) out0[o] = v;
+      } else {
+        const double ef = exp(f);
+        const double tn = dd.t[n];
+        if (live) {
+          out0[o] = v;
+          out1[o] = tn - ef / (1.0 + ef);
+          out2[o] = v * (1.0 - 2.0 * p);
+        }
+        if (n < dd.M) lj += f * tn - log(1.0 + ef);
+      }
     }
+  }
+  if (MODE == RP_F) {
+    lj = col4_sum(lj);
+    if (live && rr == 0) ljl_part[(size_t)cj * nsplit + split] = lj;
   }
 }
 
@@ -482,7 +504,7 @@ __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int 
 
 // new point: factor G(w), half log-determinant, explicit inverse, log joint, and u = G^-1 p
 // (rmhmc.py:137-138,158,166-171).  Lane j solves (L L') x = e_j: column j of G^-1.
-__global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch) {
+__global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int nsplit) {
   __shared__ double A[64 * RM_LD];
   __shared__ double Y[64 * RM_LD];
   const int D = dd.D, DP = dd.DP;
@@ -522,7 +544,7 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch) {
   if (lane < D) ch.uq[(size_t)c * DP + lane] = u;
   // log joint = sum of the row-block partials + Gaussian prior (rmhmc.py:166-169, tools.py:10-14)
   double part = 0.0;
-  for (int b = lane; b < dd.nblk; b += 64) part += ch.ljl_part[(size_t)c * dd.nblk + b];
+  for (int b = lane; b < nsplit; b += 64) part += ch.ljl_part[(size_t)c * nsplit + b];
   const double wl = (lane < D) ? ch.trj.w[(size_t)c * DP + lane] : 0.0;
   part += (lane < D) ? (dd.log_prior_const - wl * wl * 0.5 * dd.inv_alpha) : 0.0;
   const double ljl = wave_sum(part);

@@ -99,23 +99,12 @@ struct Timed {
     default: { constexpr int NB_ = 4; __VA_ARGS__; } break;               \
   }
 
-int cpg_for(const rmhmc_ctx* ctx) {
-  // chains per row-pass wave: amortise the 64-row register tile over up to 64 chains while keeping
-  // >= ~4096 waves in flight
-  long long waves1 = (long long)ctx->nblk * ctx->n;
-  long long cpg = waves1 / 4096;
-  if (cpg < 1) cpg = 1;
-  if (cpg > 64) cpg = 64;
-  return (int)cpg;
-}
-
 template <int MODE>
 void launch_rowpass(rmhmc_ctx* ctx, const double* w, double* out0, double* out1 = nullptr, double* out2 = nullptr) {
   Timed t(ctx, "rowpass");
-  const int cpg = cpg_for(ctx);
-  dim3 grid(ctx->nblk, (unsigned)((ctx->n + cpg - 1) / cpg));
-  NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<16 * NB_, MODE>), grid, dim3(64), 0, ctx->stream, ctx->dd, (int)ctx->n, cpg,
-                                     ctx->ch.phase, w, out0, out1, out2, ctx->ch.ljl_part));
+  dim3 grid((unsigned)((ctx->n + 63) / 64), ctx->nsplit);
+  NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->nsplit,
+                                    ctx->ch.phase, w, out0, out1, out2, ctx->ch.ljl_part));
 }
 
 template <bool GRAD>
@@ -154,7 +143,7 @@ void launch_eval_point(rmhmc_ctx* ctx, bool advance) {
   Chains& ch = ctx->ch;
   launch_rowpass<RP_F>(ctx, ch.trj.w, ch.rv0, ch.rv1, ch.rv2);
   launch_assemble<true>(ctx, ch.rv0, ch.rv1, ch.trj.w);
-  SMALL(ctx, "factor", k_factor_full, ctx->dd, ch);
+  SMALL(ctx, "factor", k_factor_full, ctx->dd, ch, ctx->nsplit);
   launch_mompass(ctx, ch.trj.w);
   launch_leverage(ctx);
   SMALL(ctx, "small", k_mom_final, ctx->D, ctx->DP, ch, ctx->eps, advance ? 1 : 0, ctx->nsplit);
@@ -312,8 +301,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
     RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
     RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv1, n * Mp)); RC(dalloc(ctx, &ch.rv2, n * Mp));
-    RC(dalloc(ctx, &ch.ljl_part, n * (size_t)ctx->nblk));
-    {  // row splits of the fused momentum pass: aim at >= ~6000 waves of 16 chains each
+        {  // row splits of the fused momentum pass: aim at >= ~6000 waves of 16 chains each
       const long long groups = (n_chains + 15) / 16, nb16 = ctx->Mp / 16;
       long long ns = (6144 + groups - 1) / groups;
       if (ns < 1) ns = 1;
@@ -321,6 +309,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       ctx->nsplit = (int)ns;
     }
     RC(dalloc(ctx, &ch.qpart, (size_t)ctx->nsplit * n * DP));
+    RC(dalloc(ctx, &ch.ljl_part, n * (size_t)ctx->nsplit));
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
     RC(dalloc(ctx, &ctx->d_tmpD, n * DP));
