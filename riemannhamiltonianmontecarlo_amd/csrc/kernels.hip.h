@@ -15,7 +15,7 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-#define RM_LD 65            // LDS leading dimension of the per-chain DxD matrix (65: conflict-free columns)
+#define RM_LD 66            // LDS leading dimension of the per-chain DxD matrix (even: 16-byte aligned rows for ds_read_b128, conflict free)
 #define RM_PI2 6.283185307179586476925286766559
 
 struct DevData {
@@ -40,6 +40,7 @@ struct Chains {
   // scratch
   double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv1, *rv2, *ljl_part, *qpart;
   int n;
+  int hiprio;  // light kernels raise their wave priority when they co-run with another group's MFMA kernel
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -413,56 +414,120 @@ __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, cons
 
 // ---------------------------------------------------------------------------------------------
 // small dense kernels: one chain per wavefront (64 threads per block), DxD matrix in LDS.
+// These are latency bound, so every inner loop is unrolled by 8 with all its LDS reads (ds_read_b128,
+// row stride 66 doubles: conflict free) issued before the dependent FMA chain, cross-lane broadcasts use
+// v_readlane (the index is wave uniform) instead of ds_bpermute, and divisions by the diagonal are
+// replaced by one reciprocal square root per column.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rdlane(double x, int k) {  // k must be wave uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double2 lds2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+
+// acc -= sum_{k<n} a[k]*b[k]  (a, b: LDS rows, 16-byte aligned), two accumulators
+__device__ __forceinline__ double neg_dot_lds(const double* a, const double* b, int n, double acc) {
+  double s0 = acc, s1 = 0.0;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    const double2 a0 = lds2(a + k), a1 = lds2(a + k + 2), a2 = lds2(a + k + 4), a3 = lds2(a + k + 6);
+    const double2 b0 = lds2(b + k), b1 = lds2(b + k + 2), b2 = lds2(b + k + 4), b3 = lds2(b + k + 6);
+    s0 = fma(-a0.x, b0.x, s0); s1 = fma(-a0.y, b0.y, s1);
+    s0 = fma(-a1.x, b1.x, s0); s1 = fma(-a1.y, b1.y, s1);
+    s0 = fma(-a2.x, b2.x, s0); s1 = fma(-a2.y, b2.y, s1);
+    s0 = fma(-a3.x, b3.x, s0); s1 = fma(-a3.y, b3.y, s1);
+  }
+  for (; k + 2 <= n; k += 2) {
+    const double2 a0 = lds2(a + k), b0 = lds2(b + k);
+    s0 = fma(-a0.x, b0.x, s0); s1 = fma(-a0.y, b0.y, s1);
+  }
+  if (k < n) s0 = fma(-a[k], b[k], s0);
+  return s0 + s1;
+}
+
 // lower Cholesky in place (left-looking; lane i owns row i).  np.linalg.cholesky, rmhmc.py:60,171.
-// A pivot <=0 or NaN yields NaN everywhere downstream (=> H is NaN => the proposal is rejected).
-__device__ __forceinline__ int chol_lds(double* A, int D, int lane) {
+// rdiag (lane j): 1/L[j][j].  A pivot <=0 or NaN yields NaN everywhere downstream (=> H is NaN => the
+// proposal is rejected).
+__device__ __forceinline__ int chol_lds(double* A, int D, int lane, double& rdiag) {
   int bad = 0;
+  rdiag = 1.0;
+  const double* rowp = A + lane * RM_LD;
   for (int j = 0; j < D; ++j) {
-    double s = 0.0;
-    if (lane >= j && lane < D) {
-      s = A[lane * RM_LD + j];
-      for (int k = 0; k < j; ++k) s = fma(-A[lane * RM_LD + k], A[j * RM_LD + k], s);
-    }
-    const double sjj = __shfl(s, j, 64);
+    const double s = neg_dot_lds(rowp, A + j * RM_LD, j, rowp[j]);  // meaningful for lanes j..D-1
+    const double sjj = rdlane(s, j);
     if (!(sjj > 0.0)) bad = 1;
-    const double ljj = sqrt(sjj);
-    __syncthreads();
-    if (lane >= j && lane < D) A[lane * RM_LD + j] = (lane == j) ? ljj : s / ljj;
-    __syncthreads();
+    const double rinv = rsqrt(sjj);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == j) { A[j * RM_LD + j] = sjj * rinv; rdiag = rinv; }
+    else if (lane > j && lane < D) A[lane * RM_LD + j] = s * rinv;
+    __builtin_amdgcn_wave_barrier();
   }
   return bad;
 }
-// x = (L L')^-1 b ; lane i holds b_i on entry and x_i on return
-__device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane, double b) {
-  for (int k = 0; k < D; ++k) {  // forward, column oriented
-    const double yk = __shfl(b, k, 64) / L[k * RM_LD + k];
-    if (lane == k) b = yk;
-    else if (lane > k && lane < D) b = fma(-L[lane * RM_LD + k], yk, b);
+// x = (L L')^-1 b ; lane i holds b_i on entry and x_i on return; rdiag as produced by chol_lds
+__device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane, double b, double rdiag) {
+  const double* rowp = L + lane * RM_LD;
+  int k = 0;
+  for (; k + 4 <= D; k += 4) {  // forward, column oriented; the four multipliers are fetched up front
+    const double2 l01 = lds2(rowp + k), l23 = lds2(rowp + k + 2);
+    const double lk[4] = {l01.x, l01.y, l23.x, l23.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double yk = rdlane(b, k + q) * rdlane(rdiag, k + q);
+      if (lane == k + q) b = yk;
+      else if (lane > k + q) b = fma(-lk[q], yk, b);
+    }
   }
-  for (int k = D - 1; k >= 0; --k) {  // backward with L'
-    const double xk = __shfl(b, k, 64) / L[k * RM_LD + k];
+  for (; k < D; ++k) {
+    const double yk = rdlane(b, k) * rdlane(rdiag, k);
+    if (lane == k) b = yk;
+    else if (lane > k) b = fma(-rowp[k], yk, b);
+  }
+  k = D - 1;
+  for (; k >= 3; k -= 4) {  // backward with L'
+    const double lk[4] = {L[k * RM_LD + lane], L[(k - 1) * RM_LD + lane], L[(k - 2) * RM_LD + lane], L[(k - 3) * RM_LD + lane]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double xk = rdlane(b, k - q) * rdlane(rdiag, k - q);
+      if (lane == k - q) b = xk;
+      else if (lane < k - q) b = fma(-lk[q], xk, b);
+    }
+  }
+  for (; k >= 0; --k) {
+    const double xk = rdlane(b, k) * rdlane(rdiag, k);
     if (lane == k) b = xk;
     else if (lane < k) b = fma(-L[k * RM_LD + lane], xk, b);
   }
   return b;
 }
 
+// DxD matrix (row stride DP in HBM) -> LDS, eight row loads in flight
 __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict__ G, int D, int DP, int lane) {
-  for (int i = 0; i < D; ++i)
-    if (lane < D) A[i * RM_LD + lane] = G[i * DP + lane];
-  __syncthreads();
+  const int l = lane < D ? lane : 0;
+  int i = 0;
+  for (; i + 8 <= D; i += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = G[(i + q) * DP + l];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) A[(i + q) * RM_LD + lane] = v[q];
+  }
+  for (; i < D; ++i) A[i * RM_LD + lane] = G[i * DP + l];
+  __builtin_amdgcn_wave_barrier();
 }
 
 // position fixed point, first iterate (rmhmc.py:113-122 with FixedIter = 0): G(Pw^0) = G(w) is the
 // factor already stored in the trajectory record, so u = u0 and Pw^1 = w + tau*eps*u0.
 __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps) {
-  __shared__ double A[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   load_mat_lds(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
+  const double rdiag = (lane < D) ? 1.0 / A[lane * RM_LD + lane] : 1.0;
   const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
-  const double u0 = cholsolve_lds(A, D, lane, pb);
+  const double u0 = cholsolve_lds(A, D, lane, pb, rdiag);
   if (lane < D) {
     ch.u0[(size_t)c * DP + lane] = u0;
     ch.wq[(size_t)c * DP + lane] = ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * eps * u0;
@@ -471,13 +536,15 @@ __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, doub
 
 // position fixed point, iterate k>=1 (rmhmc.py:116-122): factor G(Pw^k), solve, update Pw.
 __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, double eps) {
-  __shared__ double A[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
-  const int bad = chol_lds(A, D, lane);
+  double rdiag;
+  const int bad = chol_lds(A, D, lane, rdiag);
   const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
-  const double u = cholsolve_lds(A, D, lane, pb);
+  const double u = cholsolve_lds(A, D, lane, pb, rdiag);
   if (lane < D)
     ch.wq[(size_t)c * DP + lane] =
         ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * (eps * 0.5) * (ch.u0[(size_t)c * DP + lane] + u);
@@ -487,6 +554,7 @@ __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, d
 // accept the position iterate as the new w and apply the position guard (rmhmc.py:123-130)
 __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int guards) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   double w = (lane < D) ? ch.wq[(size_t)c * DP + lane] : 0.0;
   if (guards) {
@@ -503,46 +571,56 @@ __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int 
 }
 
 // new point: factor G(w), half log-determinant, explicit inverse, log joint, and u = G^-1 p
-// (rmhmc.py:137-138,158,166-171).  Lane j solves (L L') x = e_j: column j of G^-1.
+// (rmhmc.py:137-138,158,166-171).  Lane j solves (L L') x = e_j (column j of G^-1) and keeps its
+// solution in row j of Y.
 __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int nsplit) {
-  __shared__ double A[64 * RM_LD];
-  __shared__ double Y[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) double Y[64 * RM_LD];
   const int D = dd.D, DP = dd.DP;
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
-  const int bad = chol_lds(A, D, lane);
-  // half log det = sum log diag(L)   (rmhmc.py:171,175)
-  const double ld = (lane < D) ? log(A[lane * RM_LD + lane]) : 0.0;
-  const double hld = wave_sum(ld);
-  // inverse: forward then backward substitution, lane j owns right-hand side e_j (column j of Y)
+  double rdiag;
+  const int bad = chol_lds(A, D, lane, rdiag);
+  // half log det = sum log diag(L) = -sum log(1/L_jj)   (rmhmc.py:171,175)
+  const double hld = -wave_sum((lane < D) ? log(rdiag) : 0.0);
+  // forward substitution L y = e_lane
+  double* yrow = Y + lane * RM_LD;
   for (int i = 0; i < D; ++i) {
-    double s = (i == lane) ? 1.0 : 0.0;
-    for (int k = 0; k < i; ++k) s = fma(-A[i * RM_LD + k], Y[k * RM_LD + lane], s);
-    Y[i * RM_LD + lane] = s / A[i * RM_LD + i];
+    const double s = neg_dot_lds(A + i * RM_LD, yrow, i, (i == lane) ? 1.0 : 0.0);
+    yrow[i] = s * rdlane(rdiag, i);
   }
+  // backward substitution L' x = y
   for (int i = D - 1; i >= 0; --i) {
-    double s = Y[i * RM_LD + lane];
-    for (int k = i + 1; k < D; ++k) s = fma(-A[k * RM_LD + i], Y[k * RM_LD + lane], s);
-    Y[i * RM_LD + lane] = s / A[i * RM_LD + i];
+    double s0 = yrow[i], s1 = 0.0;
+    int k = i + 1;
+    if ((k & 1) && k < D) { s0 = fma(-A[k * RM_LD + i], yrow[k], s0); ++k; }
+    for (; k + 4 <= D; k += 4) {
+      const double l0 = A[k * RM_LD + i], l1 = A[(k + 1) * RM_LD + i], l2 = A[(k + 2) * RM_LD + i], l3 = A[(k + 3) * RM_LD + i];
+      const double2 y01 = lds2(yrow + k), y23 = lds2(yrow + k + 2);
+      s0 = fma(-l0, y01.x, s0); s1 = fma(-l1, y01.y, s1);
+      s0 = fma(-l2, y23.x, s0); s1 = fma(-l3, y23.y, s1);
+    }
+    for (; k < D; ++k) s0 = fma(-A[k * RM_LD + i], yrow[k], s0);
+    yrow[i] = (s0 + s1) * rdlane(rdiag, i);
   }
-  __syncthreads();
-  // store L (lower, zeros above) and the symmetrised inverse
+  __builtin_amdgcn_wave_barrier();
+  // store L (lower, zeros above) and the symmetrised inverse; Y[j][i] = (G^-1)[i][j]
   double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
   double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
-  for (int i = 0; i < D; ++i)
+  const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
+  double u = 0.0;
+  for (int i = 0; i < D; ++i) {
+    const double gi = 0.5 * (Y[i * RM_LD + lane] + yrow[i]);
     if (lane < D) {
       Lg[i * DP + lane] = (lane <= i) ? A[i * RM_LD + lane] : 0.0;
-      Gi[i * DP + lane] = 0.5 * (Y[i * RM_LD + lane] + Y[lane * RM_LD + i]);
+      Gi[i * DP + lane] = gi;
     }
-  // u = G^-1 p
-  double u = 0.0;
-  for (int j = 0; j < D; ++j) {
-    const double pj = ch.p[(size_t)c * DP + j];
-    if (lane < D) u = fma(0.5 * (Y[j * RM_LD + lane] + Y[lane * RM_LD + j]), pj, u);
+    u = fma(gi, rdlane(pl, i), u);  // u = G^-1 p
   }
   if (lane < D) ch.uq[(size_t)c * DP + lane] = u;
-  // log joint = sum of the row-block partials + Gaussian prior (rmhmc.py:166-169, tools.py:10-14)
+  // log joint = sum of the row-split partials + Gaussian prior (rmhmc.py:166-169, tools.py:10-14)
   double part = 0.0;
   for (int b = lane; b < nsplit; b += 64) part += ch.ljl_part[(size_t)c * nsplit + b];
   const double wl = (lane < D) ? ch.trj.w[(size_t)c * DP + lane] : 0.0;
@@ -558,6 +636,7 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int n
 // u = G^-1 v for the momentum fixed point (rmhmc.py:104); src = p (first iterate) or PM
 __global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, const double* __restrict__ src) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
   double u = 0.0;
@@ -571,6 +650,7 @@ __global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, co
 // PM = p + tau*eps/2 * (grad - tr/2 + q/2)   (rmhmc.py:108); final != 0: p = PM (rmhmc.py:110)
 __global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, double eps, int final, int nsplit) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1 || lane >= D) return;
   const size_t o = (size_t)c * DP + lane;
   const double h = ch.tau[c] * eps * 0.5;
@@ -584,6 +664,7 @@ __global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, dou
 // explicit momentum half step at the new point (rmhmc.py:163) + step bookkeeping
 __global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, double eps, int advance, int nsplit) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   const size_t o = (size_t)c * DP + lane;
   double pn = 0.0, wn = 0.0;
@@ -654,6 +735,7 @@ __device__ __forceinline__ double half_quadform(const double* __restrict__ Gi, i
 
 __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, IterParams ip) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 0) return;
   const long long it = ch.iter[c];
   if (it >= ip.iter_limit) return;
@@ -716,6 +798,7 @@ __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, Ite
 
 __global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterParams ip) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   const int ph = ch.phase[c];
   if (!(ph == 2 || (ph == 1 && ch.steps_left[c] == 0))) return;
   const long long it = ch.iter[c];

@@ -8,10 +8,13 @@
 #include "../../include/rmhmc.h"
 #include "kernels.hip.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -22,17 +25,35 @@ char g_err[512] = "";
 
 struct EvPair { hipEvent_t a, b; };
 
+// A contiguous range of chains with its own view of the per-chain arrays.  Large batches are split into
+// two groups that are ping-ponged: the heavy matrix-core kernels of both groups run back to back on the
+// main stream while each group's light kernels (Cholesky, vector updates, transition control) run on a
+// side stream under the other group's heavy kernel; per-group events carry the dependencies.
+struct Group {
+  Chains ch{};
+  int n = 0;
+  long long off = 0;
+  int nsplit = 1;
+  std::vector<hipEvent_t> ring;
+  size_t ring_pos = 0;
+  int prev = -1;  // stream of the group's previous launch: 0 main, 1 side, -1 none since the last fork
+};
+
+enum Cls { HEAVY = 0, LIGHT = 1 };
+
 }  // namespace
 
 struct rmhmc_ctx {
   int device = 0;
   int64_t M = 0, n = 0;
-  int D = 0, DP = 0, NB = 0, Mp = 0, nblk = 0, nsplit = 1;
+  int D = 0, DP = 0, NB = 0, Mp = 0, nblk = 0;
   uint32_t flags = 0;
   double alpha = 100.0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, side = nullptr;
+  hipEvent_t fj_event = nullptr;
   DevData dd{};
-  Chains ch{};
+  Chains ch{};  // whole-batch view (uploads / downloads)
+  std::vector<Group> groups;
   std::vector<void*> allocs;
   bool have_data = false, chains_ready = false;
   // sampler parameters of the stateful API
@@ -41,7 +62,7 @@ struct rmhmc_ctx {
   uint64_t seed = 0;
   int64_t chain_offset = 0;
   // unit-API staging (device)
-  double *d_z = nullptr, *d_ulen = nullptr, *d_gdir = nullptr, *d_uacc = nullptr, *d_tmpD = nullptr;
+  double *d_z = nullptr, *d_ulen = nullptr, *d_gdir = nullptr, *d_uacc = nullptr;
   int *d_nsteps = nullptr, *d_dir = nullptr, *d_done = nullptr;
   long long* d_steps0 = nullptr;
   // timing
@@ -78,19 +99,53 @@ int dalloc(rmhmc_ctx* ctx, T** p, size_t count) {
 
 struct Timed {
   rmhmc_ctx* ctx;
+  hipStream_t st;
   EvPair ev{};
   bool on;
-  Timed(rmhmc_ctx* c, const char* name) : ctx(c), on(c->timing) {
+  Timed(rmhmc_ctx* c, const char* name, hipStream_t s) : ctx(c), st(s), on(c->timing) {
     if (!on) return;
     if (!ctx->pool.empty()) { ev = ctx->pool.back(); ctx->pool.pop_back(); }
     else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
-    (void)hipEventRecord(ev.a, ctx->stream);
+    (void)hipEventRecord(ev.a, st);
     ctx->events[name].push_back(ev);
   }
-  ~Timed() { if (on) (void)hipEventRecord(ev.b, ctx->stream); }
+  ~Timed() { if (on) (void)hipEventRecord(ev.b, st); }
 };
 
-// ---- launch helpers -----------------------------------------------------------------------------
+// ---- stream plumbing ------------------------------------------------------------------------------
+// fork: work issued to the side stream from now on is ordered after everything already on the main
+// stream (uploads, fills); join: the main stream waits for the side stream (before downloads).
+void fork_streams(rmhmc_ctx* ctx) {
+  for (Group& g : ctx->groups) g.prev = -1;
+  if (ctx->groups.size() < 2) return;
+  (void)hipEventRecord(ctx->fj_event, ctx->stream);
+  (void)hipStreamWaitEvent(ctx->side, ctx->fj_event, 0);
+}
+void join_streams(rmhmc_ctx* ctx) {
+  if (ctx->groups.size() < 2) return;
+  (void)hipEventRecord(ctx->fj_event, ctx->side);
+  (void)hipStreamWaitEvent(ctx->stream, ctx->fj_event, 0);
+  for (Group& g : ctx->groups) g.prev = -1;
+}
+
+// Launch one kernel of group g.  fn(stream) enqueues it.
+template <typename F>
+void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
+  const bool multi = ctx->groups.size() > 1;
+  const int which = (multi && cls == LIGHT) ? 1 : 0;
+  hipStream_t st = which ? ctx->side : ctx->stream;
+  if (multi && g.prev >= 0 && g.prev != which) (void)hipStreamWaitEvent(st, g.ring[g.ring_pos % g.ring.size()], 0);
+  {
+    Timed t(ctx, name, st);
+    fn(st);
+  }
+  if (multi) {
+    g.ring_pos++;
+    (void)hipEventRecord(g.ring[g.ring_pos % g.ring.size()], st);
+    g.prev = which;
+  }
+}
+
 #define NB_SWITCH(ctx, ...)                                               \
   switch ((ctx)->NB) {                                                    \
     case 1: { constexpr int NB_ = 1; __VA_ARGS__; } break;                \
@@ -100,100 +155,138 @@ struct Timed {
   }
 
 template <int MODE>
-void launch_rowpass(rmhmc_ctx* ctx, const double* w, double* out0, double* out1 = nullptr, double* out2 = nullptr) {
-  Timed t(ctx, "rowpass");
-  dim3 grid((unsigned)((ctx->n + 63) / 64), ctx->nsplit);
-  NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->nsplit,
-                                    ctx->ch.phase, w, out0, out1, out2, ctx->ch.ljl_part));
+void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out1 = nullptr, double* out2 = nullptr) {
+  launch(ctx, g, HEAVY, "rowpass", [&](hipStream_t st) {
+    dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
+    NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
+                                      out1, out2, g.ch.ljl_part));
+  });
 }
 
 template <bool GRAD>
-void launch_assemble(rmhmc_ctx* ctx, const double* v, const double* r, const double* w) {
-  Timed t(ctx, "assemble");
-  dim3 grid((unsigned)((ctx->n + 3) / 4));
-  NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_, GRAD>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n,
-                                     ctx->ch.phase, v, r, w, ctx->ch.Gq, ctx->ch.trj.grad));
+void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, const double* r, const double* w) {
+  launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
+    dim3 grid((unsigned)((g.n + 3) / 4));
+    NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_, GRAD>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, r, w, g.ch.Gq,
+                                      g.ch.trj.grad));
+  });
 }
 
 // q partials of u' dG/dw_d u for every chain (u = ch.uq, w as given); summed by k_mom_update / k_mom_final
-void launch_mompass(rmhmc_ctx* ctx, const double* w) {
-  Timed t(ctx, "mompass");
-  dim3 grid((unsigned)((ctx->n + 63) / 64), ctx->nsplit);
-  NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->nsplit, w,
-                                    ctx->ch.uq, ctx->ch.qpart));
+void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w) {
+  launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
+    dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
+    NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart));
+  });
 }
 
-void launch_leverage(rmhmc_ctx* ctx) {
-  Timed t(ctx, "leverage");
-  dim3 grid((unsigned)((ctx->n + 3) / 4));
-  NB_SWITCH(ctx, hipLaunchKernelGGL((k_leverage<NB_>), grid, dim3(256), 0, ctx->stream, ctx->dd, (int)ctx->n, ctx->ch.phase,
-                                     ctx->ch.trj.Ginv, ctx->ch.rv2, ctx->ch.trj.tr));
+void launch_leverage(rmhmc_ctx* ctx, Group& g) {
+  launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
+    dim3 grid((unsigned)((g.n + 3) / 4));
+    NB_SWITCH(ctx, hipLaunchKernelGGL((k_leverage<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.Ginv, g.ch.rv2,
+                                      g.ch.trj.tr));
+  });
 }
 
-#define SMALL(ctx, name, kern, ...)                                                               \
-  do {                                                                                            \
-    Timed t_(ctx, name);                                                                          \
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ctx)->n), dim3(64), 0, (ctx)->stream, __VA_ARGS__);  \
-  } while (0)
+// one wavefront (64-thread block) per chain
+#define SMALL(ctx, g, name, kern, ...)                                                                     \
+  launch(ctx, g, LIGHT, name, [&](hipStream_t st_) { hipLaunchKernelGGL(kern, dim3((unsigned)(g).n), dim3(64), 0, st_, __VA_ARGS__); })
 
-// Evaluate the point record at trj.w for every chain in phase 1 (rmhmc.py:134-161 minus the momentum
-// update): v, r, log-joint partials -> G and gradient on the matrix cores -> factor / inverse /
-// u = G^-1 p -> c, c(x.u)^2 -> leverage pass -> trace and quadratic terms.
-void launch_eval_point(rmhmc_ctx* ctx, bool advance) {
-  Chains& ch = ctx->ch;
-  launch_rowpass<RP_F>(ctx, ch.trj.w, ch.rv0, ch.rv1, ch.rv2);
-  launch_assemble<true>(ctx, ch.rv0, ch.rv1, ch.trj.w);
-  SMALL(ctx, "factor", k_factor_full, ctx->dd, ch, ctx->nsplit);
-  launch_mompass(ctx, ch.trj.w);
-  launch_leverage(ctx);
-  SMALL(ctx, "small", k_mom_final, ctx->D, ctx->DP, ch, ctx->eps, advance ? 1 : 0, ctx->nsplit);
+// A phase is one launch per group; phases are issued group-alternating so that, with two groups, the main
+// stream sees heavy(A), heavy(B), heavy(A), ... and the light kernels of a group overlap the other's heavy one.
+using Phase = std::function<void(Group&)>;
+void run_phases(rmhmc_ctx* ctx, const std::vector<Phase>& phases) {
+  for (const Phase& ph : phases)
+    for (Group& g : ctx->groups) ph(g);
+}
+
+// Evaluate the point record at trj.w for every chain in phase 1 (rmhmc.py:134-161; with advance the
+// explicit momentum half step :163 too): v, r, c, log-joint partials -> G and gradient on the matrix cores
+// -> factor / inverse / u = G^-1 p -> quadratic term -> leverage pass (trace term) -> momentum update.
+void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance) {
+  ph.push_back([ctx](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv1, g.ch.rv2); });
+  ph.push_back([ctx](Group& g) { launch_assemble<true>(ctx, g, g.ch.rv0, g.ch.rv1, g.ch.trj.w); });
+  ph.push_back([ctx](Group& g) { SMALL(ctx, g, "factor", k_factor_full, ctx->dd, g.ch, g.nsplit); });
+  ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
+  ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
+  ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
 }
 
 // One generalised leapfrog step for every chain in phase 1 (rmhmc.py:96-163).
-void launch_step(rmhmc_ctx* ctx) {
-  Chains& ch = ctx->ch;
+void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   const int D = ctx->D, DP = ctx->DP, K = ctx->K;
   const double eps = ctx->eps;
   // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
   for (int it = 0; it < K; ++it) {
-    SMALL(ctx, "small", k_ginv_matvec, D, DP, ch, it == 0 ? ch.p : ch.PM);
-    launch_mompass(ctx, ch.trj.w);
-    SMALL(ctx, "small", k_mom_update, D, DP, ch, eps, it == K - 1 ? 1 : 0, ctx->nsplit);
+    ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, it == 0 ? g.ch.p : g.ch.PM); });
+    ph.push_back([=](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
+    ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_mom_update, D, DP, g.ch, eps, it == K - 1 ? 1 : 0, g.nsplit); });
   }
   // implicit position step: K fixed-point iterations (rmhmc.py:113-123); the first one re-uses the
   // stored factor of G(w)
-  SMALL(ctx, "factor", k_pos_first, D, DP, ch, eps);
+  ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_pos_first, D, DP, g.ch, eps); });
   for (int it = 1; it < K; ++it) {
-    launch_rowpass<RP_V>(ctx, ch.wq, ch.rv0);
-    launch_assemble<false>(ctx, ch.rv0, nullptr, nullptr);
-    SMALL(ctx, "factor", k_factor_solve, D, DP, ch, eps);
+    ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0); });
+    ph.push_back([=](Group& g) { launch_assemble<false>(ctx, g, g.ch.rv0, nullptr, nullptr); });
+    ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_factor_solve, D, DP, g.ch, eps); });
   }
-  SMALL(ctx, "small", k_pos_final, D, DP, ch, (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0);
+  const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
+  ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_pos_final, D, DP, g.ch, guards); });
   // explicit momentum half step at the new point (rmhmc.py:134-163)
-  launch_eval_point(ctx, true);
+  eval_point_phases(ctx, ph, true);
 }
 
-IterParams iter_params(rmhmc_ctx* ctx, long long limit, long long burn_in, long long S, double* samples, bool explicit_rng) {
+void launch_eval_point(rmhmc_ctx* ctx) {
+  std::vector<Phase> ph;
+  eval_point_phases(ctx, ph, false);
+  run_phases(ctx, ph);
+}
+void launch_step(rmhmc_ctx* ctx) {
+  std::vector<Phase> ph;
+  step_phases(ctx, ph);
+  run_phases(ctx, ph);
+}
+
+struct IterBase {
+  long long limit, burn_in, S;
+  double* samples;
+  bool explicit_rng;
+  bool count_done;
+};
+
+IterParams iter_params(rmhmc_ctx* ctx, const Group& g, const IterBase& b) {
   IterParams ip{};
   ip.flags = ctx->flags;
   ip.L = ctx->L;
   ip.seed = ctx->seed;
-  ip.chain_offset = ctx->chain_offset;
-  ip.iter_limit = limit;
-  ip.burn_in = burn_in;
-  ip.S = S;
-  ip.samples = samples;
-  if (explicit_rng) { ip.z_in = ctx->d_z; ip.ulen_in = ctx->d_ulen; ip.gdir_in = ctx->d_gdir; ip.uacc_in = ctx->d_uacc; }
-  ip.done_count = ctx->d_done;
+  ip.chain_offset = ctx->chain_offset + g.off;
+  ip.iter_limit = b.limit;
+  ip.burn_in = b.burn_in;
+  ip.S = b.S;
+  ip.samples = b.samples ? b.samples + (size_t)g.off * b.S * ctx->D : nullptr;
+  if (b.explicit_rng) {
+    ip.z_in = ctx->d_z + (size_t)g.off * ctx->D; ip.ulen_in = ctx->d_ulen + g.off; ip.gdir_in = ctx->d_gdir + g.off; ip.uacc_in = ctx->d_uacc + g.off;
+  }
+  ip.done_count = b.count_done ? ctx->d_done : nullptr;
   return ip;
 }
 
-void launch_global_step(rmhmc_ctx* ctx, const IterParams& ip) {
-  SMALL(ctx, "small", k_iter_begin, ctx->D, ctx->DP, ctx->ch, ip);
-  launch_step(ctx);
-  SMALL(ctx, "small", k_iter_end, ctx->D, ctx->DP, ctx->ch, ip);
+void launch_iter_begin(rmhmc_ctx* ctx, const IterBase& b) {
+  for (Group& g : ctx->groups) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_iter_begin, ctx->D, ctx->DP, g.ch, ip); }
+}
+void launch_iter_end(rmhmc_ctx* ctx, const IterBase& b) {
+  for (Group& g : ctx->groups) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_iter_end, ctx->D, ctx->DP, g.ch, ip); }
 }
 
+void launch_global_step(rmhmc_ctx* ctx, const IterBase& b) {
+  std::vector<Phase> ph;
+  ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_iter_begin, ctx->D, ctx->DP, g.ch, ip); });
+  step_phases(ctx, ph);
+  ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_iter_end, ctx->D, ctx->DP, g.ch, ip); });
+  run_phases(ctx, ph);
+}
+
+// whole-batch helpers on the main stream (callers fork/join around group work)
 void fill_int(rmhmc_ctx* ctx, int* p, int v, size_t n) {
   hipLaunchKernelGGL(k_fill_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, v, n);
 }
@@ -224,6 +317,7 @@ int upload(rmhmc_ctx* ctx, T* dst, const T* src, size_t count) {
 }
 
 int sync(rmhmc_ctx* ctx) {
+  if (ctx->side) HIPCK(hipStreamSynchronize(ctx->side));
   HIPCK(hipStreamSynchronize(ctx->stream));
   HIPCK(hipGetLastError());
   return RMHMC_OK;
@@ -237,7 +331,8 @@ int sync(rmhmc_ctx* ctx) {
     HIPCK(hipSetDevice((ctx)->device));                                             \
   } while (0)
 
-// upload w into trj.w, zero (or upload) p, mark every chain active, evaluate the record
+// upload w into trj.w, zero (or upload) p, mark every chain active, evaluate the record.
+// Leaves the streams forked: callers join before downloading.
 int eval_at(rmhmc_ctx* ctx, const double* w, const double* p) {
   Chains& ch = ctx->ch;
   RC(upload_vec(ctx, ch.trj.w, w));
@@ -245,8 +340,28 @@ int eval_at(rmhmc_ctx* ctx, const double* w, const double* p) {
   else HIPCK(hipMemsetAsync(ch.p, 0, sizeof(double) * ctx->n * ctx->DP, ctx->stream));
   fill_int(ctx, ch.phase, 1, ctx->n);
   fill_int(ctx, ch.status, 0, ctx->n);
-  launch_eval_point(ctx, false);
+  fork_streams(ctx);
+  launch_eval_point(ctx);
   return RMHMC_OK;
+}
+
+// view of the per-chain arrays for chains [off, off+n)
+Chains chains_view(const rmhmc_ctx* ctx, long long off, int n) {
+  const size_t DP = ctx->DP, Mp = ctx->Mp;
+  Chains v = ctx->ch;
+  auto vec = [&](double* p) { return p + off * DP; };
+  auto mat = [&](double* p) { return p + off * DP * DP; };
+  for (Rec* r : {&v.cur, &v.trj}) {
+    r->w = vec(r->w); r->grad = vec(r->grad); r->tr = vec(r->tr); r->L = mat(r->L); r->Ginv = mat(r->Ginv);
+    r->ljl += off; r->hld += off;
+  }
+  v.p = vec(v.p); v.p0 = vec(v.p0); v.Hcur += off; v.Hprop += off; v.tau += off;
+  v.steps_left += off; v.phase += off; v.status += off; v.nsteps_last += off;
+  v.iter += off; v.accepted += off; v.steps_done += off;
+  v.wq = vec(v.wq); v.uq = vec(v.uq); v.PM = vec(v.PM); v.u0 = vec(v.u0); v.q = vec(v.q); v.last = vec(v.last);
+  v.Gq = mat(v.Gq); v.rv0 += off * Mp; v.rv1 += off * Mp; v.rv2 += off * Mp;
+  v.n = n;
+  return v;
 }
 
 }  // namespace
@@ -301,18 +416,42 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
     RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
     RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv1, n * Mp)); RC(dalloc(ctx, &ch.rv2, n * Mp));
-        {  // row splits of the fused momentum pass: aim at >= ~6000 waves of 16 chains each
-      const long long groups = (n_chains + 15) / 16, nb16 = ctx->Mp / 16;
-      long long ns = (6144 + groups - 1) / groups;
+    // chain groups: ping-ponged partitions (RMHMC_GROUPS=1..4).  Measured on MI355X at config 3: no gain (the
+    // co-running light kernels are starved and the heavy ones slow down, profiles/r01_groups_sweep.txt), so
+    // the default is a single group on one stream.
+    int ngroups = 1;
+    if (const char* e = getenv("RMHMC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 4) ngroups = v; }
+    if (n_chains < 64 * ngroups) ngroups = 1;
+    int hiprio = ngroups > 1 ? 1 : 0;
+    if (const char* e = getenv("RMHMC_PRIO")) hiprio = atoi(e) ? 1 : 0;
+    ctx->groups.resize(ngroups);
+    const long long per_group = ((n_chains / ngroups + 63) / 64) * 64;  // leading groups: a multiple of 64 chains
+    for (int gi = 0; gi < ngroups; ++gi) {
+      Group& g = ctx->groups[gi];
+      g.off = std::min<long long>((long long)gi * per_group, n_chains);
+      g.n = (int)((gi == ngroups - 1) ? n_chains - g.off : std::min<long long>(per_group, n_chains - g.off));
+      if (g.n <= 0) return fail(ctx, RMHMC_ERR_INVALID, "internal: empty chain group");
+      // row splits of the 16-chains-per-wave passes: aim at >= ~6000 waves per launch
+      const long long cgroups = (g.n + 15) / 16, nb16 = ctx->Mp / 16;
+      long long ns = (6144 / ngroups + cgroups - 1) / cgroups;
       if (ns < 1) ns = 1;
       if (ns > nb16) ns = nb16;
-      ctx->nsplit = (int)ns;
+      g.nsplit = (int)ns;
+      g.ch = chains_view(ctx, g.off, g.n);
+      g.ch.hiprio = hiprio;
+      RC(dalloc(ctx, &g.ch.qpart, (size_t)g.nsplit * g.n * DP));
+      RC(dalloc(ctx, &g.ch.ljl_part, (size_t)g.n * g.nsplit));
+      if (ngroups > 1) {
+        g.ring.resize(64);
+        for (auto& e : g.ring) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
     }
-    RC(dalloc(ctx, &ch.qpart, (size_t)ctx->nsplit * n * DP));
-    RC(dalloc(ctx, &ch.ljl_part, n * (size_t)ctx->nsplit));
+    if (ngroups > 1) {
+      HIPCK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+      HIPCK(hipEventCreateWithFlags(&ctx->fj_event, hipEventDisableTiming));
+    }
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
-    RC(dalloc(ctx, &ctx->d_tmpD, n * DP));
     RC(sync(ctx));
     return RMHMC_OK;
   };
@@ -330,6 +469,10 @@ void rmhmc_destroy(rmhmc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+  for (Group& g : ctx->groups) for (auto& e : g.ring) (void)hipEventDestroy(e);
+  if (ctx->fj_event) (void)hipEventDestroy(ctx->fj_event);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& kv : ctx->events) for (auto& e : kv.second) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (void* p : ctx->allocs) (void)hipFree(p);
@@ -343,7 +486,7 @@ int rmhmc_device_info(rmhmc_ctx* ctx, char* buf, size_t len) {
   HIPCK(hipGetDeviceProperties(&prop, ctx->device));
   snprintf(buf, len, "%s %s, %d CUs, %.0f MHz, %.1f GiB; M=%lld (padded %d) D=%d (padded %d, %d MFMA tiles) chains=%lld",
            prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0,
-           (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n);
+           (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n, (int)ctx->groups.size());
   return RMHMC_OK;
 }
 
@@ -377,6 +520,7 @@ int rmhmc_log_posterior(rmhmc_ctx* ctx, const double* w, double* ljl_out) {
   if (!w || !ljl_out) return fail(ctx, RMHMC_ERR_INVALID, "log_posterior: null pointer");
   ctx->chains_ready = false;
   RC(eval_at(ctx, w, nullptr));
+  join_streams(ctx);
   RC(download(ctx, ljl_out, ctx->ch.trj.ljl, ctx->n));
   return sync(ctx);
 }
@@ -386,6 +530,7 @@ int rmhmc_metric(rmhmc_ctx* ctx, const double* w, double* G_out, double* half_lo
   if (!w) return fail(ctx, RMHMC_ERR_INVALID, "metric: null pointer");
   ctx->chains_ready = false;
   RC(eval_at(ctx, w, nullptr));
+  join_streams(ctx);
   if (G_out)
     for (int64_t c = 0; c < ctx->n; ++c)  // strip the padding: [DP][DP] -> [D][D]
       HIPCK(hipMemcpy2DAsync(G_out + c * ctx->D * ctx->D, ctx->D * 8, ctx->ch.Gq + c * ctx->DP * ctx->DP, ctx->DP * 8, ctx->D * 8, ctx->D,
@@ -400,6 +545,7 @@ int rmhmc_metric_terms(rmhmc_ctx* ctx, const double* w, const double* p, double*
   if (!w) return fail(ctx, RMHMC_ERR_INVALID, "metric_terms: null pointer");
   ctx->chains_ready = false;
   RC(eval_at(ctx, w, p));
+  join_streams(ctx);
   if (trace_out) RC(download_vec(ctx, trace_out, ctx->ch.trj.tr));
   if (quad_out && p) RC(download_vec(ctx, quad_out, ctx->ch.last));
   return sync(ctx);
@@ -416,15 +562,21 @@ int rmhmc_leapfrog(rmhmc_ctx* ctx, double* w, double* p, double eps, const int32
     if (nsteps[c] > maxs) maxs = nsteps[c];
   }
   ctx->eps = eps; ctx->K = K;
-  RC(eval_at(ctx, w, p));
   RC(upload(ctx, ctx->d_nsteps, nsteps, ctx->n));
   RC(upload(ctx, ctx->d_dir, dir, ctx->n));
-  const unsigned g = (unsigned)((ctx->n + 255) / 256);
-  hipLaunchKernelGGL(k_set_leapfrog, dim3(g), dim3(256), 0, ctx->stream, (int)ctx->n, ctx->d_nsteps, ctx->d_dir, ctx->ch);
+  RC(eval_at(ctx, w, p));
+  for (Group& g : ctx->groups)
+    launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
+      hipLaunchKernelGGL(k_set_leapfrog, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.n, ctx->d_nsteps + g.off, ctx->d_dir + g.off, g.ch);
+    });
   for (int s = 0; s < maxs; ++s) {
     launch_step(ctx);
-    hipLaunchKernelGGL(k_park_finished, dim3(g), dim3(256), 0, ctx->stream, (int)ctx->n, ctx->ch);
+    for (Group& g : ctx->groups)
+      launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
+        hipLaunchKernelGGL(k_park_finished, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.n, g.ch);
+      });
   }
+  join_streams(ctx);
   RC(download_vec(ctx, w, ctx->ch.trj.w));
   RC(download_vec(ctx, p, ctx->ch.p));
   if (half_logdet_out) RC(download(ctx, half_logdet_out, ctx->ch.trj.hld, ctx->n));
@@ -441,7 +593,8 @@ static int init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] or NU
     theta0_host = th.data();
   }
   RC(eval_at(ctx, theta0_host, nullptr));
-  SMALL(ctx, "small", k_commit_all, ctx->D, ctx->DP, ctx->ch);
+  for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_commit_all, ctx->D, ctx->DP, g.ch);
+  join_streams(ctx);
   fill_int(ctx, ctx->ch.phase, 0, ctx->n);
   fill_int(ctx, ctx->ch.steps_left, 0, ctx->n);
   fill_int(ctx, ctx->ch.status, 0, ctx->n);
@@ -464,13 +617,15 @@ int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u
   RC(upload(ctx, ctx->d_ulen, u_len, ctx->n));
   RC(upload(ctx, ctx->d_gdir, g_dir, ctx->n));
   RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
-  IterParams ip = iter_params(ctx, 1, 0, 0, nullptr, true);
-  SMALL(ctx, "small", k_iter_begin, ctx->D, ctx->DP, ctx->ch, ip);
-  SMALL(ctx, "small", k_iter_end, ctx->D, ctx->DP, ctx->ch, ip);  // trajectories of zero steps
+  const IterBase ib{1, 0, 0, nullptr, true, false};
+  fork_streams(ctx);
+  launch_iter_begin(ctx, ib);
+  launch_iter_end(ctx, ib);  // trajectories of zero steps
   for (int s = 0; s < L; ++s) {
     launch_step(ctx);
-    SMALL(ctx, "small", k_iter_end, ctx->D, ctx->DP, ctx->ch, ip);
+    launch_iter_end(ctx, ib);
   }
+  join_streams(ctx);
   std::vector<long long> acc(ctx->n);
   RC(download_vec(ctx, w, ctx->ch.cur.w));
   RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
@@ -487,18 +642,21 @@ int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u
 }
 
 // ---- bulk entry points --------------------------------------------------------------------------
-static int run_until_done(rmhmc_ctx* ctx, const IterParams& ip, long long min_steps) {
+static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_steps) {
   // every chain needs at least min_steps more global steps; afterwards poll the done counter
   int done = 0;
   long long s = 0;
   const int poll = 4;
+  fork_streams(ctx);
   for (;;) {
-    launch_global_step(ctx, ip);
+    launch_global_step(ctx, ib);
     ++s;
     if (s >= min_steps && (s - min_steps) % poll == 0) {
+      join_streams(ctx);
       HIPCK(hipMemcpyAsync(&done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       RC(sync(ctx));
       if (done >= ctx->n) break;
+      fork_streams(ctx);
     }
     if (s > min_steps * (long long)ctx->L + 1000000) return fail(ctx, RMHMC_ERR_RUNTIME, "sampler did not terminate");
   }
@@ -520,14 +678,14 @@ int rmhmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, dou
     RC(init_chains(ctx, theta0));
     // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
     // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
-    IterParams ipA = iter_params(ctx, burn_in + 1, burn_in, S, d_samples, false);
+    const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
     RC(run_until_done(ctx, ipA, burn_in + 1));
     HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
     RC(sync(ctx));
     const auto t0 = std::chrono::steady_clock::now();
     if (n_iter > burn_in + 1) {
-      IterParams ipB = iter_params(ctx, n_iter, burn_in, S, d_samples, false);
+      const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
       RC(run_until_done(ctx, ipB, n_iter - burn_in - 1));
     }
     RC(sync(ctx));
@@ -561,11 +719,12 @@ int rmhmc_chains_init(rmhmc_ctx* ctx, const double* theta0, uint64_t seed, int64
 int rmhmc_chains_run(rmhmc_ctx* ctx, int64_t n_steps) {
   NEED_DATA(ctx);
   if (!ctx->chains_ready) return fail(ctx, RMHMC_ERR_INVALID, "chains_run: rmhmc_chains_init has not been called");
-  IterParams ip = iter_params(ctx, (long long)1 << 62, 0, 0, nullptr, false);
-  ip.done_count = nullptr;
+  const IterBase ib{(long long)1 << 62, 0, 0, nullptr, false, false};
+  fork_streams(ctx);
   {
-    Timed t(ctx, "total");
-    for (int64_t s = 0; s < n_steps; ++s) launch_global_step(ctx, ip);
+    Timed t(ctx, "total", ctx->stream);
+    for (int64_t s = 0; s < n_steps; ++s) launch_global_step(ctx, ib);
+    join_streams(ctx);
   }
   return sync(ctx);
 }

@@ -250,3 +250,25 @@ def test_errors(hip):
             ctx.leapfrog(np.zeros((1, 2)), np.zeros((1, 2)), 0.5, 1, 1, K=0)
         with pytest.raises(_capi.RmhmcError):
             ctx.chains_run(1)                       # chains_init not called
+
+
+def test_two_group_pingpong_matches_oracle(hip, oracle, monkeypatch):
+    """Large batches are split into two chain groups ping-ponged over two HIP streams; force that
+    scheduling at a small size and check transitions, the sampler and the stepping API against the oracle."""
+    monkeypatch.setenv("RMHMC_GROUPS", "2")
+    M, D, n = 500, 20, 150
+    rs = np.random.RandomState(21)
+    w = 0.1 * rs.randn(n, D); z = rs.randn(n, D); ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
+
+    def fn(ctx):
+        if "group" in ctx.device_info():
+            assert "2 group" in ctx.device_info()
+        r = ctx.transition(w, z, ul, gd, ua, L=4, eps=0.5, K=4)
+        s = ctx.sample(6, 2, L=3, seed=5, chain_offset=7)
+        return r, s
+
+    (rg, sg), (ro, so) = _both(hip, oracle, M, D, n, fn)
+    assert np.array_equal(rg["nsteps"], ro["nsteps"]) and np.array_equal(rg["accepted"], ro["accepted"])
+    assert rel_err(rg["w_prop"], ro["w_prop"]) < TOL_TRAJ and rel_err(rg["p_prop"], ro["p_prop"]) < TOL_TRAJ
+    assert rel_err(rg["w"], ro["w"]) < TOL_TRAJ
+    assert np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2]) and rel_err(sg[0], so[0]) < 1e-7
