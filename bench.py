@@ -60,12 +60,17 @@ def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0):
     cores = min(avail, int(os.environ.get("RMHMC_CPU_THREADS", "16")))  # one GPU's CPU share on the box is 16 cores
     os.environ["OMP_NUM_THREADS"] = str(cores)
     M, D = XX.shape
-    n = cores
+    # calibrate on `cores` chains x 2 steps, then size the sample (chains x steps) for about budget_s seconds
+    with oracle.context(M, D, cores, flags=flags) as ctx:
+        ctx.set_data(XX, t)
+        ctx.chains_init(seed=1, L=L, eps=eps, K=K)
+        t0 = time.perf_counter(); ctx.chains_run(2); rate = cores * 2 / max(time.perf_counter() - t0, 1e-9)
+    total = max(rate * budget_s, cores)
+    steps = int(min(50, max(1, total // cores)))
+    n = int(min(8192, max(cores, (total // steps) // cores * cores)))
     with oracle.context(M, D, n, flags=flags) as ctx:
         ctx.set_data(XX, t)
         ctx.chains_init(seed=1, L=L, eps=eps, K=K)
-        t0 = time.perf_counter(); ctx.chains_run(1); dt1 = time.perf_counter() - t0
-        steps = int(max(1, min(200, budget_s / max(dt1, 1e-6))))
         t0 = time.perf_counter(); ctx.chains_run(steps); dt = time.perf_counter() - t0
     return {"value": n * steps / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
             "sample": "%d chains x %d leapfrog steps of the same (M=%d, D=%d) workload, matrix-free C oracle, OpenMP over chains, %.1f s"

@@ -337,13 +337,16 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
 
 // ---------------------------------------------------------------------------------------------
 // K4  leverage pass on the matrix cores: h_n = x_n' G^-1 x_n for every data row, then
-//       tr_d   = sum_n c_n h_n x_nd          (= tr(G^-1 dG/dw_d),      rmhmc.py:67-77,148-156)
-// Y = X * Ghat with Ghat the block-upper-triangular fold of the symmetric G^-1 (off-diagonal
-// blocks doubled) so only NB(NB+1)/2 blocks are multiplied; h = rowsum(Y .* X).
-// Blocks use the same column permutation as k_assemble (block I = columns NB*m + I).
-// Per 16 data rows: A operand X[n0+(lane&15)][NB*(4s+(lane>>4)) + I]  (s = 0..3),
-//                   B operand Ghat[NB*(4s+(lane>>4)) + I][NB*(lane&15) + J]  (held in registers),
-//                   Y_J[r] = Y[n0+(lane>>4)+4r][NB*(lane&15)+J].
+//       tr_d = sum_n c_n h_n x_nd          (= tr(G^-1 dG/dw_d),      rmhmc.py:67-77,148-156)
+// The transposed product Y' = Ghat' X' is computed (Ghat = block-upper-triangular fold of the symmetric
+// G^-1 with off-diagonal blocks doubled, so only NB(NB+1)/2 blocks are multiplied; blocks use the column
+// permutation of k_assemble: block I = columns NB*m + I).  Per 16 data rows:
+//   B operand  X[n0+(lane&15)][NB*(4s+(lane>>4)) + I]          (s = 0..3)   -- the only copy of X loaded
+//   A operand  Ghat[NB*(4s+(lane>>4)) + I][NB*(lane&15) + J]                 -- chain constant, 80 VGPRs
+//   result     Y'_J[r] = Y[n0+(lane&15)][NB*((lane>>4)+4r) + J]
+// i.e. accumulator register r of tile J sits in the lane that holds x at the very same (row, column) in
+// operand register (s = r, I = J): h is a per-lane dot product plus a 4-lane sum, and the trace
+// accumulation re-uses the operand registers.
 // ---------------------------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, const int* __restrict__ phase,
@@ -356,8 +359,7 @@ __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, cons
   if (phase[c] != 1) return;
   const int rr = lane >> 4, ci = lane & 15;
   const double* __restrict__ Gi = Ginv + (size_t)c * DP * DP;
-  // B operands
-  double Bv[NB][4][NB];
+  double Gv[NB][4][NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -365,25 +367,27 @@ __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, cons
 #pragma unroll
       for (int J = 0; J < NB; ++J) {
         const int row = NB * (4 * s + rr) + I, col = NB * ci + J;
-        Bv[I][s][J] = (J >= I) ? Gi[row * DP + col] * (I == J ? 1.0 : 2.0) : 0.0;
+        Gv[I][s][J] = (J >= I) ? Gi[row * DP + col] * (I == J ? 1.0 : 2.0) : 0.0;
       }
-  const double* __restrict__ xa_p = dd.Xr + (size_t)ci * DP + NB * rr;       // A layout: row n0+ci, col NB*(4s+rr)+I
-  const double* __restrict__ xc_p = dd.Xr + (size_t)rr * DP + NB * ci;       // C layout: row n0+rr+4r, col NB*ci+J
-  const double* __restrict__ cp = crow + (size_t)c * dd.Mp + rr;
-  double tracc[NB];
+  const double* __restrict__ xp = dd.Xr + (size_t)ci * DP + NB * rr;  // row n0+ci, column NB*(4s+rr)+I
+  const double* __restrict__ cp = crow + (size_t)c * dd.Mp + ci;
+  double tracc[4][NB];
 #pragma unroll
-  for (int J = 0; J < NB; ++J) tracc[J] = 0.0;
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int J = 0; J < NB; ++J) tracc[r][J] = 0.0;
 
-  for (int n0 = 0; n0 < dd.Mp; n0 += 16) {
-    double A[4][NB], Xc[4][NB];
+  // software pipeline over 16-row blocks (Mp is a multiple of 64, so blocks come in pairs): the operand
+  // loads of the next block are issued before the MFMAs of the current one
+  double XA[4][NB], XB[4][NB], cA, cB;
+  auto load_block = [&](double (&X)[4][NB], double& cn, int n0) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) A[s][I] = xa_p[(size_t)n0 * DP + NB * 4 * s + I];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int J = 0; J < NB; ++J) Xc[r][J] = xc_p[(size_t)(n0 + 4 * r) * DP + J];
+      for (int I = 0; I < NB; ++I) X[s][I] = xp[(size_t)n0 * DP + NB * 4 * s + I];
+    cn = cp[n0];
+  };
+  auto compute_block = [&](const double (&X)[4][NB], double cn) {
     d4 Y[NB];
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
@@ -391,25 +395,34 @@ __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, cons
 #pragma unroll
       for (int I = 0; I <= J; ++I)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) Y[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s][I], Bv[I][s][J], Y[J], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) Y[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gv[I][s][J], X[s][I], Y[J], 0, 0, 0);
     }
+    double hp = 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double hp = 0.0;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int J = 0; J < NB; ++J) hp = fma(Y[J][r], Xc[r][J], hp);
-      const double h = row16_sum(hp);
-      const double ch = cp[n0 + 4 * r] * h;
+      for (int J = 0; J < NB; ++J) hp = fma(Y[J][r], X[r][J], hp);
+    const double ch = cn * col4_sum(hp);  // leverage of row n0+ci, times c
 #pragma unroll
-      for (int J = 0; J < NB; ++J) tracc[J] = fma(ch, Xc[r][J], tracc[J]);
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) tracc[r][J] = fma(ch, X[r][J], tracc[r][J]);
+  };
+  load_block(XA, cA, 0);
+  for (int n0 = 0; n0 < dd.Mp; n0 += 32) {
+    load_block(XB, cB, n0 + 16);
+    compute_block(XA, cA);
+    if (n0 + 32 < dd.Mp) load_block(XA, cA, n0 + 32);
+    compute_block(XB, cB);
   }
 #pragma unroll
-  for (int J = 0; J < NB; ++J) {
-    const double a = col4_sum(tracc[J]);
-    const int d = NB * ci + J;
-    if (rr == 0 && d < dd.D) tr[(size_t)c * DP + d] = a;
-  }
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      const double a = row16_sum(tracc[r][J]);
+      const int d = NB * (4 * r + rr) + J;
+      if (ci == 0 && d < dd.D) tr[(size_t)c * DP + d] = a;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
