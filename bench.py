@@ -60,18 +60,20 @@ def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0):
     cores = min(avail, int(os.environ.get("RMHMC_CPU_THREADS", "16")))  # one GPU's CPU share on the box is 16 cores
     os.environ["OMP_NUM_THREADS"] = str(cores)
     M, D = XX.shape
-    # calibrate on `cores` chains x 2 steps, then size the sample (chains x steps) for about budget_s seconds
-    with oracle.context(M, D, cores, flags=flags) as ctx:
-        ctx.set_data(XX, t)
-        ctx.chains_init(seed=1, L=L, eps=eps, K=K)
-        t0 = time.perf_counter(); ctx.chains_run(2); rate = cores * 2 / max(time.perf_counter() - t0, 1e-9)
-    total = max(rate * budget_s, cores)
-    steps = int(min(50, max(1, total // cores)))
-    n = int(min(8192, max(cores, (total // steps) // cores * cores)))
-    with oracle.context(M, D, n, flags=flags) as ctx:
-        ctx.set_data(XX, t)
-        ctx.chains_init(seed=1, L=L, eps=eps, K=K)
-        t0 = time.perf_counter(); ctx.chains_run(steps); dt = time.perf_counter() - t0
+    # grow the sample (steps up to 50, then chains) until it takes a good fraction of budget_s
+    n, steps, dt = cores, 2, 0.0
+    for _ in range(6):
+        with oracle.context(M, D, n, flags=flags) as ctx:
+            ctx.set_data(XX, t)
+            ctx.chains_init(seed=1, L=L, eps=eps, K=K)
+            t0 = time.perf_counter(); ctx.chains_run(steps); dt = time.perf_counter() - t0
+        if dt >= budget_s / 3 or n >= 8192:
+            break
+        grow = min(16.0, budget_s / max(dt, 1e-6))
+        new_steps = int(min(50, max(steps, steps * grow)))
+        grow /= new_steps / steps
+        steps = new_steps
+        n = int(min(8192, max(n, int(n * grow) // cores * cores)))
     return {"value": n * steps / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
             "sample": "%d chains x %d leapfrog steps of the same (M=%d, D=%d) workload, matrix-free C oracle, OpenMP over chains, %.1f s"
                       % (n, steps, M, D, dt)}
@@ -86,6 +88,8 @@ def main():
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--compat", type=int, default=0, help="1: reference-compatible momentum (L'z) and guards; 0: corrected (default, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ess-iters", type=int, default=0,
+                    help="if >0: also run RMHMC for this many post-burn-in transitions (+100 burn-in) per chain and report min-ESS/sec")
     args = ap.parse_args()
 
     import torch
@@ -150,6 +154,22 @@ def main():
         if rank == 0:
             finite = finite and all(bool(torch.isfinite(g).all()) for g in gathered)
 
+    ess = None
+    if args.ess_iters > 0:
+        # second half of the metric: sum over chains of (min over dims of the per-chain ESS) / seconds of the
+        # post-burn-in phase (TimeTaken semantics, rmhmc.py:194-198).  ESS by tools.CalculateESS semantics with
+        # the MATLAB FFT length (no wrap-around); estimated on a subset of chains to bound the host FFT work.
+        from riemannhamiltonianmontecarlo_amd import tools
+        burn = 100
+        smp, acc_s, steps_s, secs = ctx.sample(burn + args.ess_iters, burn, L=L, eps=eps, K=K, seed=7, chain_offset=rank * n)
+        sub = smp[:: max(1, n // 256)]
+        me = tools.min_ess_per_chain(sub, nfft="matlab")
+        ess = {"min_ess_per_sec": float(me.mean() * n * world / secs), "seconds": secs, "post_burn_in_transitions": args.ess_iters,
+               "mean_min_ess_per_chain": float(me.mean()), "chains_used_for_estimate": int(sub.shape[0]),
+               "leapfrog_steps_per_sec_during_sampling": float(steps_s.sum() * world / secs),
+               "acceptance": float(acc_s.sum()) / float((burn + args.ess_iters) * n),
+               "note": "per-chain ESS (MATLAB CalculateStatistics.m semantics), summed over chains; rank-0 shard scaled by world size"}
+
     if rank == 0:
         total_steps = world * n * args.steps
         value = total_steps / elapsed
@@ -184,6 +204,8 @@ def main():
             "kernel_seconds": {k: {"seconds": v[0], "launches": v[1]} for k, v in kt.items()},
             "all_finite": finite, "acceptance_rate": acc_rate,
         }
+        if ess is not None:
+            out["min_ess"] = ess
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(XX, t, flags, L, eps, K)
         print(json.dumps(out))

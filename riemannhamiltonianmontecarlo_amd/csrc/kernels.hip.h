@@ -38,7 +38,7 @@ struct Chains {
   int *steps_left, *phase, *status, *nsteps_last;
   long long *iter, *accepted, *steps_done;
   // scratch
-  double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv1, *rv2, *ljl_part, *qpart;
+  double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv2, *ljl_part, *qpart, *gpart;
   int n;
   int hiprio;  // light kernels raise their wave priority when they co-run with another group's MFMA kernel
 };
@@ -94,8 +94,9 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 // MFMA tile, K = D), then the per-(row, chain) scalars the other kernels consume.  Replaces the f/p/v
 // blocks of rmhmc.py:51-53,99-100,116-118,134-136,166-168 and the c = v(1-2p) factor of :67,:148.
 //   RP_V : out0 = v_n = p(1-p),  p = 1/(1+e^-f),  f = x_n.wq                          (rmhmc.py:116-118)
-//   RP_F : out0 = v_n, out1 = t_n - e^f/(1+e^f) (rmhmc.py:140), out2 = c_n, log-joint partial sums
-//          sum_n f t - log(1+e^f) per (chain, row split)                               (rmhmc.py:167-168)
+//   RP_F : out0 = v_n, out2 = c_n, partial sums over the row split of the likelihood gradient
+//          X'(t - e^f/(1+e^f)) (rmhmc.py:100,140; a fourth small GEMM whose B operand is the accumulator
+//          layout of F, as in k_mompass) and of the log joint sum_n f t - log(1+e^f)   (rmhmc.py:167-168)
 // The naive exp/log forms are kept on purpose: they overflow exactly where the reference does.
 // Accumulator register r of lane l holds data row (l>>4)+4r of the tile and chain l&15.
 // ---------------------------------------------------------------------------------------------
@@ -104,7 +105,7 @@ enum { RP_V = 0, RP_F = 1 };
 template <int NB, int MODE>
 __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
-                                                 double* __restrict__ out1, double* __restrict__ out2,
+                                                 double* __restrict__ out2, double* __restrict__ gpart,
                                                  double* __restrict__ ljl_part) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
@@ -122,12 +123,23 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
   const int per = (nb16 + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(nb16, b0 + per);
   const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + ci;  // A: X[n0+ci][4kk+rr]
+  const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;   // A of the gradient product
   double lj = 0.0;
+  d4 Gr[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) Gr[I] = (d4){0.0, 0.0, 0.0, 0.0};
   for (int b = b0; b < b1; ++b) {
     const int n0 = b * 16;
     double A[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + n0];
+    double xb[4][NB];
+    if (MODE == RP_F) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + 4 * r) * DP + I];
+    }
     d4 F = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
@@ -146,22 +158,33 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
         const double tn = dd.t[n];
         if (live) {
           out0[o] = v;
-          out1[o] = tn - ef / (1.0 + ef);
           out2[o] = v * (1.0 - 2.0 * p);
         }
         if (n < dd.M) lj += f * tn - log(1.0 + ef);
+        const double rn = tn - ef / (1.0 + ef);  // padded rows: x = 0, no contribution
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rn, Gr[I], 0, 0, 0);
       }
     }
   }
   if (MODE == RP_F) {
     lj = col4_sum(lj);
     if (live && rr == 0) ljl_part[(size_t)cj * nsplit + split] = lj;
+    if (live) {
+      double* __restrict__ out = gpart + ((size_t)split * n_chains + c0 + ci) * DP;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = NB * (rr + 4 * r) + I;
+          if (d < dd.D) out[d] = Gr[I][r];
+        }
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2  metric assembly  G = X' diag(v) X + I/alpha  on the fp64 matrix cores (rmhmc.py:57,119,137),
-// optionally fused with the likelihood gradient X' r - w/alpha (rmhmc.py:100,140).
+// K2  metric assembly  G = X' diag(v) X + I/alpha  on the fp64 matrix cores (rmhmc.py:57,119,137).
 // One chain per wavefront.  v_mfma_f64_16x16x4_f64: A[i][k], B[k][j] one f64 per lane with
 // i/j = lane&15, k = lane>>4; D[(lane>>4)+4r][lane&15] in accumulator register r.
 // Column permutation: tile index I in [0,NB) and in-tile index i map to column NB*i + I, so a
@@ -169,11 +192,9 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
 // bytes per step) and the same registers serve as A (scaled by v_n) and B operands.
 // Only tiles I<=J are computed (G is symmetric): NB(NB+1)/2 MFMAs per 4 data rows.
 // ---------------------------------------------------------------------------------------------
-template <int NB, bool GRAD>
+template <int NB>
 __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, const int* __restrict__ phase,
-                                                  const double* __restrict__ vrow, const double* __restrict__ rrow,
-                                                  const double* __restrict__ wq, double* __restrict__ Gq,
-                                                  double* __restrict__ grad) {
+                                                  const double* __restrict__ vrow, double* __restrict__ Gq) {
   constexpr int DP = 16 * NB;
   constexpr int NT = NB * (NB + 1) / 2;
   const int lane = threadIdx.x & 63;
@@ -183,36 +204,26 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
   const int rr = lane >> 4, ci = lane & 15;
   const double* __restrict__ xp = dd.Xr + (size_t)rr * DP + NB * ci;
   const double* __restrict__ vp = vrow + (size_t)c * dd.Mp + rr;
-  const double* __restrict__ rp = GRAD ? (rrow + (size_t)c * dd.Mp + rr) : nullptr;
   d4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-  double gacc[NB];
-#pragma unroll
-  for (int I = 0; I < NB; ++I) gacc[I] = 0.0;
-
   // Software pipeline over 16-row groups (4 MFMA k-chunks of 4 data rows): the loads of the next group are
   // issued before the 4*NT MFMAs of the current one.  Mp is a multiple of 64, so groups come in pairs.
-  double xbA[4][NB], vA[4], rA[4], xbB[4][NB], vB[4], rB[4];
-  auto load_group = [&](double (&xb)[4][NB], double (&vv)[4], double (&rv)[4], int n1) {
+  double xbA[4][NB], vA[4], xbB[4][NB], vB[4];
+  auto load_group = [&](double (&xb)[4][NB], double (&vv)[4], int n1) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
       for (int I = 0; I < NB; ++I) xb[q][I] = xp[(size_t)(n1 + 4 * q) * DP + I];
       vv[q] = vp[n1 + 4 * q];
-      if (GRAD) rv[q] = rp[n1 + 4 * q];
     }
   };
-  auto compute_group = [&](const double (&xb)[4][NB], const double (&vv)[4], const double (&rv)[4]) {
+  auto compute_group = [&](const double (&xb)[4][NB], const double (&vv)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       double xa[NB];
 #pragma unroll
       for (int I = 0; I < NB; ++I) xa[I] = vv[q] * xb[q][I];
-      if (GRAD) {
-#pragma unroll
-        for (int I = 0; I < NB; ++I) gacc[I] = fma(rv[q], xb[q][I], gacc[I]);
-      }
       int t = 0;
 #pragma unroll
       for (int I = 0; I < NB; ++I)
@@ -223,12 +234,12 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
         }
     }
   };
-  load_group(xbA, vA, rA, 0);
+  load_group(xbA, vA, 0);
   for (int n1 = 0; n1 < dd.Mp; n1 += 32) {
-    load_group(xbB, vB, rB, n1 + 16);
-    compute_group(xbA, vA, rA);
-    if (n1 + 32 < dd.Mp) load_group(xbA, vA, rA, n1 + 32);
-    compute_group(xbB, vB, rB);
+    load_group(xbB, vB, n1 + 16);
+    compute_group(xbA, vA);
+    if (n1 + 32 < dd.Mp) load_group(xbA, vA, n1 + 32);
+    compute_group(xbB, vB);
   }
   // epilogue: scatter the permuted tiles into the natural row-major DPxDP matrix (+ I/alpha)
   double* __restrict__ G = Gq + (size_t)c * DP * DP;
@@ -252,14 +263,6 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
       }
       ++t;
     }
-  if (GRAD) {
-#pragma unroll
-    for (int I = 0; I < NB; ++I) {
-      const double g = col4_sum(gacc[I]);
-      const int d = NB * ci + I;
-      if (rr == 0 && d < dd.D) grad[(size_t)c * DP + d] = g - wq[(size_t)c * DP + d] * dd.inv_alpha;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -637,6 +640,12 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int n
   double part = 0.0;
   for (int b = lane; b < nsplit; b += 64) part += ch.ljl_part[(size_t)c * nsplit + b];
   const double wl = (lane < D) ? ch.trj.w[(size_t)c * DP + lane] : 0.0;
+  // gradient = X'(t - s) - w/alpha (rmhmc.py:100,140): sum of the row-split partials of k_rowpass<RP_F>
+  if (lane < D) {
+    double g = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) g += ch.gpart[((size_t)sp * ch.n + c) * DP + lane];
+    ch.trj.grad[(size_t)c * DP + lane] = g - wl * dd.inv_alpha;
+  }
   part += (lane < D) ? (dd.log_prior_const - wl * wl * 0.5 * dd.inv_alpha) : 0.0;
   const double ljl = wave_sum(part);
   if (lane == 0) {

@@ -155,20 +155,18 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
   }
 
 template <int MODE>
-void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out1 = nullptr, double* out2 = nullptr) {
+void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out2 = nullptr) {
   launch(ctx, g, HEAVY, "rowpass", [&](hipStream_t st) {
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                      out1, out2, g.ch.ljl_part));
+                                      out2, g.ch.gpart, g.ch.ljl_part));
   });
 }
 
-template <bool GRAD>
-void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, const double* r, const double* w) {
+void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
   launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
     dim3 grid((unsigned)((g.n + 3) / 4));
-    NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_, GRAD>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, r, w, g.ch.Gq,
-                                      g.ch.trj.grad));
+    NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, g.ch.Gq));
   });
 }
 
@@ -204,8 +202,8 @@ void run_phases(rmhmc_ctx* ctx, const std::vector<Phase>& phases) {
 // explicit momentum half step :163 too): v, r, c, log-joint partials -> G and gradient on the matrix cores
 // -> factor / inverse / u = G^-1 p -> quadratic term -> leverage pass (trace term) -> momentum update.
 void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance) {
-  ph.push_back([ctx](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv1, g.ch.rv2); });
-  ph.push_back([ctx](Group& g) { launch_assemble<true>(ctx, g, g.ch.rv0, g.ch.rv1, g.ch.trj.w); });
+  ph.push_back([ctx](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv2); });
+  ph.push_back([ctx](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
   ph.push_back([ctx](Group& g) { SMALL(ctx, g, "factor", k_factor_full, ctx->dd, g.ch, g.nsplit); });
   ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
   ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
@@ -227,7 +225,7 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_pos_first, D, DP, g.ch, eps); });
   for (int it = 1; it < K; ++it) {
     ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0); });
-    ph.push_back([=](Group& g) { launch_assemble<false>(ctx, g, g.ch.rv0, nullptr, nullptr); });
+    ph.push_back([=](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
     ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_factor_solve, D, DP, g.ch, eps); });
   }
   const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
@@ -359,7 +357,7 @@ Chains chains_view(const rmhmc_ctx* ctx, long long off, int n) {
   v.steps_left += off; v.phase += off; v.status += off; v.nsteps_last += off;
   v.iter += off; v.accepted += off; v.steps_done += off;
   v.wq = vec(v.wq); v.uq = vec(v.uq); v.PM = vec(v.PM); v.u0 = vec(v.u0); v.q = vec(v.q); v.last = vec(v.last);
-  v.Gq = mat(v.Gq); v.rv0 += off * Mp; v.rv1 += off * Mp; v.rv2 += off * Mp;
+  v.Gq = mat(v.Gq); v.rv0 += off * Mp; v.rv2 += off * Mp;
   v.n = n;
   return v;
 }
@@ -415,7 +413,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     RC(dalloc(ctx, &ch.nsteps_last, n)); RC(dalloc(ctx, &ch.iter, n)); RC(dalloc(ctx, &ch.accepted, n)); RC(dalloc(ctx, &ch.steps_done, n));
     RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
     RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
-    RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv1, n * Mp)); RC(dalloc(ctx, &ch.rv2, n * Mp));
+    RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv2, n * Mp));
     // chain groups: ping-ponged partitions (RMHMC_GROUPS=1..4).  Measured on MI355X at config 3: no gain (the
     // co-running light kernels are starved and the heavy ones slow down, profiles/r01_groups_sweep.txt), so
     // the default is a single group on one stream.
@@ -440,6 +438,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       g.ch = chains_view(ctx, g.off, g.n);
       g.ch.hiprio = hiprio;
       RC(dalloc(ctx, &g.ch.qpart, (size_t)g.nsplit * g.n * DP));
+      RC(dalloc(ctx, &g.ch.gpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.ljl_part, (size_t)g.n * g.nsplit));
       if (ngroups > 1) {
         g.ring.resize(64);
