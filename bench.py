@@ -140,7 +140,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kt = {k: ctx.kernel_time(k) for k in ("assemble", "leverage", "rowpass", "mompass", "factor", "small", "total")}
+    kt = {k: ctx.kernel_time(k) for k in ("assemble", "leverage", "rowpass", "mompass", "factor", "small", "fused", "total")}
     ctx.kernel_time("disable")
     w_end, iters, acc = ctx.chains_state()
     finite = bool(np.isfinite(w_end).all())
@@ -178,7 +178,20 @@ def main():
         a_s, a_n = kt["assemble"]
         pass_bytes = 8.0 * M * D * n       # one assembly launch = one pass over X for every chain on this GPU
         roof = None
-        if a_n > 0:
+        f_s, f_n = kt["fused"]
+        if f_n > 0:
+            # small-problem path: one kernel does everything; a launch covers `steps` leapfrog steps of every chain
+            f_avg = f_s / f_n
+            units = n * args.steps / f_n
+            achieved = units * bytes_step / f_avg
+            roof = {"bound": "hbm", "kernel": "k_fused_small (whole leapfrog step, X resident in LDS, fp64 VALU)",
+                    "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                    "avg_launch_ms": f_avg * 1e3, "launches": f_n,
+                    "fp64_tflops": units * flops_step / f_avg / 1e12, "fp64_frac": units * flops_step / f_avg / FP64_MFMA_PEAK,
+                    "note": "achieved = algorithmic bytes (80*M*D per chain per leapfrog step, SURVEY 8(d)) / measured launch time; "
+                            "X (64 KB at config 2) is loaded into LDS once per launch, so real HBM traffic is ~0 and the kernel is "
+                            "bound by fp64 VALU issue and exp/log latency, not by HBM"}
+        elif a_n > 0:
             a_avg = a_s / a_n
             achieved = pass_bytes / a_avg
             roof = {"bound": "hbm", "kernel": "k_assemble (X' diag(v) X on fp64 MFMA)", "achieved": achieved / 1e9,

@@ -7,6 +7,7 @@
 // chain executes one leapfrog step per "global step" whatever its RandomStep.
 #include "../../include/rmhmc.h"
 #include "kernels.hip.h"
+#include "fused_small.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -56,6 +57,8 @@ struct rmhmc_ctx {
   std::vector<Group> groups;
   std::vector<void*> allocs;
   bool have_data = false, chains_ready = false;
+  bool fused = false;        // small-problem path: D <= 8 and X fits in LDS (fused_small.hip.h)
+  size_t fused_lds = 0;
   // sampler parameters of the stateful API
   int L = 6, K = 4;
   double eps = 0.5;
@@ -284,6 +287,23 @@ void launch_global_step(rmhmc_ctx* ctx, const IterBase& b) {
   run_phases(ctx, ph);
 }
 
+// Small-problem path: one launch = `nsteps` global steps of every chain (fused_small.hip.h).
+void launch_fused(rmhmc_ctx* ctx, const IterBase& b, long long nsteps) {
+  while (nsteps > 0) {
+    const int chunk = (int)std::min<long long>(nsteps, 4096);
+    for (Group& g : ctx->groups) {
+      FusedParams fp{};
+      fp.ip = iter_params(ctx, g, b);
+      fp.eps = ctx->eps; fp.K = ctx->K; fp.nsteps = chunk; fp.DPs = ctx->DP;
+      launch(ctx, g, HEAVY, "fused", [&](hipStream_t st) {
+        hipLaunchKernelGGL(k_fused_small, dim3((unsigned)((g.n + FS_WAVES - 1) / FS_WAVES)), dim3(64 * FS_WAVES), ctx->fused_lds, st,
+                           ctx->dd, g.ch, fp);
+      });
+    }
+    nsteps -= chunk;
+  }
+}
+
 // whole-batch helpers on the main stream (callers fork/join around group work)
 void fill_int(rmhmc_ctx* ctx, int* p, int v, size_t n) {
   hipLaunchKernelGGL(k_fill_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, v, n);
@@ -451,6 +471,16 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     }
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
+    {  // small-problem path eligibility (RMHMC_FUSED=0 disables it)
+      const size_t lds = ((size_t)(FS_D + 1 + FS_WAVES) * ctx->Mp + (size_t)FS_WAVES * FS_PT) * sizeof(double);
+      bool on = (D <= FS_D) && lds <= 160 * 1024;
+      if (const char* e = getenv("RMHMC_FUSED")) on = on && atoi(e) != 0;
+      if (on) {
+        HIPCK(hipFuncSetAttribute((const void*)k_fused_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->fused = true;
+        ctx->fused_lds = lds;
+      }
+    }
     RC(sync(ctx));
     return RMHMC_OK;
   };
@@ -483,9 +513,9 @@ int rmhmc_device_info(rmhmc_ctx* ctx, char* buf, size_t len) {
   if (!ctx || !buf) return fail(ctx, RMHMC_ERR_INVALID, "device_info: bad argument");
   hipDeviceProp_t prop;
   HIPCK(hipGetDeviceProperties(&prop, ctx->device));
-  snprintf(buf, len, "%s %s, %d CUs, %.0f MHz, %.1f GiB; M=%lld (padded %d) D=%d (padded %d, %d MFMA tiles) chains=%lld",
+  snprintf(buf, len, "%s %s, %d CUs, %.0f MHz, %.1f GiB; M=%lld (padded %d) D=%d (padded %d, %d MFMA tiles) chains=%lld in %d group(s)%s",
            prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0,
-           (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n, (int)ctx->groups.size());
+           (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n, (int)ctx->groups.size(), ctx->fused ? ", fused small-problem path" : "");
   return RMHMC_OK;
 }
 
@@ -618,11 +648,15 @@ int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u
   RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
   const IterBase ib{1, 0, 0, nullptr, true, false};
   fork_streams(ctx);
-  launch_iter_begin(ctx, ib);
-  launch_iter_end(ctx, ib);  // trajectories of zero steps
-  for (int s = 0; s < L; ++s) {
-    launch_step(ctx);
-    launch_iter_end(ctx, ib);
+  if (ctx->fused) {
+    launch_fused(ctx, ib, L);
+  } else {
+    launch_iter_begin(ctx, ib);
+    launch_iter_end(ctx, ib);  // trajectories of zero steps
+    for (int s = 0; s < L; ++s) {
+      launch_step(ctx);
+      launch_iter_end(ctx, ib);
+    }
   }
   join_streams(ctx);
   std::vector<long long> acc(ctx->n);
@@ -647,6 +681,20 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
   long long s = 0;
   const int poll = 4;
   fork_streams(ctx);
+  if (ctx->fused) {  // one launch for the guaranteed part, then short launches until every chain is done
+    launch_fused(ctx, ib, min_steps);
+    s = min_steps;
+    for (;;) {
+      join_streams(ctx);
+      HIPCK(hipMemcpyAsync(&done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      RC(sync(ctx));
+      if (done >= ctx->n) return RMHMC_OK;
+      fork_streams(ctx);
+      launch_fused(ctx, ib, 4 * poll);
+      s += 4 * poll;
+      if (s > min_steps * (long long)ctx->L + 1000000) return fail(ctx, RMHMC_ERR_RUNTIME, "sampler did not terminate");
+    }
+  }
   for (;;) {
     launch_global_step(ctx, ib);
     ++s;
@@ -722,7 +770,8 @@ int rmhmc_chains_run(rmhmc_ctx* ctx, int64_t n_steps) {
   fork_streams(ctx);
   {
     Timed t(ctx, "total", ctx->stream);
-    for (int64_t s = 0; s < n_steps; ++s) launch_global_step(ctx, ib);
+    if (ctx->fused) launch_fused(ctx, ib, n_steps);
+    else for (int64_t s = 0; s < n_steps; ++s) launch_global_step(ctx, ib);
     join_streams(ctx);
   }
   return sync(ctx);

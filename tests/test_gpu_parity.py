@@ -163,7 +163,8 @@ def test_stepping_api_matches_sampler(hip):
     for c in range(n):
         k = min(len(seen[c]), 8)
         assert k >= 5
-        assert np.array_equal(np.array(seen[c][:k]), s[c, :k])
+        # launches resume trajectories from the state arrays; agreement is to the last bit or two
+        assert np.allclose(np.array(seen[c][:k]), s[c, :k], rtol=1e-12, atol=1e-14)
 
 
 def test_full_size_config3_properties(hip, oracle):
@@ -261,7 +262,7 @@ def test_two_group_pingpong_matches_oracle(hip, oracle, monkeypatch):
     w = 0.1 * rs.randn(n, D); z = rs.randn(n, D); ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
 
     def fn(ctx):
-        if "group" in ctx.device_info():
+        if "MFMA" in ctx.device_info():   # the HIP library (the oracle reports its OpenMP threads)
             assert "2 group" in ctx.device_info()
         r = ctx.transition(w, z, ul, gd, ua, L=4, eps=0.5, K=4)
         s = ctx.sample(6, 2, L=3, seed=5, chain_offset=7)
@@ -272,3 +273,51 @@ def test_two_group_pingpong_matches_oracle(hip, oracle, monkeypatch):
     assert rel_err(rg["w_prop"], ro["w_prop"]) < TOL_TRAJ and rel_err(rg["p_prop"], ro["p_prop"]) < TOL_TRAJ
     assert rel_err(rg["w"], ro["w"]) < TOL_TRAJ
     assert np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2]) and rel_err(sg[0], so[0]) < 1e-7
+
+
+@pytest.mark.parametrize("M,D,n,flags", [(1000, 8, 37, _capi.COMPAT), (532, 8, 9, 0), (300, 5, 6, _capi.COMPAT), (70, 1, 4, 0),
+                                         (1500, 3, 5, _capi.COMPAT)])
+def test_fused_small_path_matches_oracle_and_generic(hip, oracle, monkeypatch, M, D, n, flags):
+    """BASELINE config-2 path (D <= 8, X in LDS, one fused kernel for many steps): whole sampled chains against
+    the oracle (same Philox streams) and against the generic multi-kernel path."""
+    def fn(ctx):
+        info = ctx.device_info()
+        r = ctx.sample(12, 3, L=4, seed=23, chain_offset=5)
+        ctx.chains_init(seed=4)
+        ctx.chains_run(9)
+        return info, r, ctx.chains_state()
+
+    (ig, rg, sg), (io, ro, so) = _both(hip, oracle, M, D, n, fn, flags=flags, seed=9)
+    assert "fused" in ig
+    assert np.array_equal(rg[1], ro[1]) and np.array_equal(rg[2], ro[2])
+    assert rel_err(rg[0], ro[0]) < 1e-7
+    assert np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2]) and rel_err(sg[0], so[0]) < 1e-7
+    monkeypatch.setenv("RMHMC_FUSED", "0")
+    XX, t = synthetic_logreg(M, D, 9)
+    with hip.context(M, D, n, flags=flags) as ctx:
+        ctx.set_data(XX, t)
+        assert "fused" not in ctx.device_info()
+        r2 = ctx.sample(12, 3, L=4, seed=23, chain_offset=5)
+    assert np.array_equal(r2[1], rg[1]) and rel_err(r2[0], rg[0]) < 1e-7
+
+
+def test_fused_path_momentum_guard_and_mixed_api(hip, oracle):
+    """Guards inside the fused kernel (|p| > 100 on strongly scaled data) and hand-over between the fused
+    stepping kernel and the generic unit entry points on the same context."""
+    M, D, n = 400, 6, 8
+    XX, t = synthetic_logreg(M, D, 12)
+    XX = XX * 25.0
+    outs = []
+    for lib in (hip, oracle):
+        with lib.context(M, D, n, flags=_capi.COMPAT) as ctx:
+            ctx.set_data(XX, t)
+            ctx.chains_init(seed=2, eps=0.3)
+            ctx.chains_run(5)
+            w, it, acc = ctx.chains_state()
+            G, hld, g = ctx.metric(w)          # generic kernels on the state the fused kernel left
+            ctx.chains_init(theta0=w, seed=3, eps=0.3)
+            ctx.chains_run(4)
+            outs.append((w, it, acc, hld, ctx.chains_state()[0]))
+    (wg, ig, ag, hg, w2g), (wo, io, ao, ho, w2o) = outs
+    assert np.array_equal(ig, io) and np.array_equal(ag, ao)
+    assert rel_err(wg, wo) < 1e-7 and rel_err(hg, ho) < 1e-7 and rel_err(w2g, w2o) < 1e-6
