@@ -160,6 +160,26 @@ int rmhmc_chains_state(rmhmc_ctx *ctx, double *w_out, int64_t *iters_out,
 int rmhmc_kernel_time(rmhmc_ctx *ctx, const char *which, double *seconds_out,
                       int64_t *launches_out);
 
+/* ---- widening, SURVEY.md 8(f)-1: plain HMC with identity mass, code/hmc.py:12-99 ------------------
+ * Same data, context and conventions as above.  Differences from RMHMC that the reference has and that are
+ * kept: trajectory length RandomStep = ceil(u_len*L) with L = 100 by default and no direction flip
+ * (hmc.py:48), theta0 = 0 (hmc.py:27), a NaN momentum ends the trajectory (hmc.py:56-57) and the proposal
+ * is then rejected.                                                                                    */
+
+/* hmc.py:41-80 with caller-supplied randomness (draw order hmc.py:41,48,77):
+ *   z[n*D] ~ randn(1,D), u_len[n] ~ rand(), u_acc[n] ~ rand().  w in/out; outputs optional.            */
+int rmhmc_hmc_transition(rmhmc_ctx *ctx, double *w, const double *z, const double *u_len,
+                         const double *u_acc, int32_t L, double eps, int32_t *accepted_out,
+                         int32_t *nsteps_out, double *H_cur_out, double *H_prop_out,
+                         double *w_prop_out, double *p_prop_out);
+
+/* HMC(XX, t, n_iter, burn_in, L, eps) for all chains; arguments as rmhmc_sample
+ * (theta0 NULL: zeros, hmc.py:27).                                                                     */
+int rmhmc_hmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps,
+                     uint64_t seed, int64_t chain_offset, const double *theta0,
+                     double *samples_out, int64_t *accept_out, int64_t *steps_out,
+                     double *seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

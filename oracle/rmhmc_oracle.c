@@ -830,6 +830,103 @@ int rmhmc_kernel_time(rmhmc_ctx *ctx, const char *which, double *seconds_out, in
   return fail(ctx, RMHMC_ERR_UNSUPPORTED, "no kernels in the CPU oracle");
 }
 
+/* ------------------------------------------------------------------------ */
+/* plain HMC, identity mass: restatement of code/hmc.py:12-99                */
+/* ------------------------------------------------------------------------ */
+/* One transition from w (log joint ljl_w).  hmc.py:41-80.  Returns accepted; w_prop/p_prop = end of the
+ * trajectory.  The gradient is re-evaluated at both ends of every step exactly like the reference. */
+static int hmc_transition(const rmhmc_ctx *c, const double *w, double ljl_w, const double *z, double u_len, double u_acc,
+                          int L, double eps, double *w_prop, double *p_prop, double *g /* D scratch */, int *nsteps_out,
+                          double *Hc_out, double *Hp_out, double *ljl_prop_out) {
+  const int D = c->D;
+  memcpy(w_prop, w, sizeof(double) * D);
+  memcpy(p_prop, z, sizeof(double) * D);                 /* Mass = I: p = z (hmc.py:41) */
+  const double Hc = -ljl_w + 0.5 * dot(D, z, z);          /* hmc.py:72 */
+  const int nsteps = (int)ceil(u_len * L);                /* hmc.py:48 */
+  for (int s = 0; s < nsteps; s++) {
+    gradient(c, w_prop, g);                               /* hmc.py:52-53 */
+    for (int d = 0; d < D; d++) p_prop[d] += eps / 2 * g[d];
+    int nan = 0;
+    for (int d = 0; d < D; d++) if (p_prop[d] != p_prop[d]) nan = 1;
+    if (nan) break;                                       /* hmc.py:56-57 */
+    for (int d = 0; d < D; d++) w_prop[d] += eps * p_prop[d];
+    gradient(c, w_prop, g);                               /* hmc.py:60-61 */
+    for (int d = 0; d < D; d++) p_prop[d] += eps / 2 * g[d];
+  }
+  const double ljl_p = log_joint(c, w_prop);              /* hmc.py:64-67 */
+  const double Hp = -ljl_p + 0.5 * dot(D, p_prop, p_prop); /* hmc.py:69 */
+  const double ratio = -Hp + Hc;
+  *nsteps_out = nsteps; *Hc_out = Hc; *Hp_out = Hp; *ljl_prop_out = ljl_p;
+  return (ratio > 0) || (ratio > log(u_acc));             /* hmc.py:77 */
+}
+
+int rmhmc_hmc_transition(rmhmc_ctx *ctx, double *w, const double *z, const double *u_len, const double *u_acc, int32_t L,
+                         double eps, int32_t *accepted_out, int32_t *nsteps_out, double *H_cur_out, double *H_prop_out,
+                         double *w_prop_out, double *p_prop_out) {
+  NEED_DATA(ctx);
+  const int D = ctx->D;
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    double *wp = (double *)malloc(sizeof(double) * D), *pp = (double *)malloc(sizeof(double) * D), *g = (double *)malloc(sizeof(double) * D);
+    int ns; double Hc, Hp, lj;
+    const int acc = hmc_transition(ctx, &w[c * D], log_joint(ctx, &w[c * D]), &z[c * D], u_len[c], u_acc[c], L, eps, wp, pp, g, &ns, &Hc, &Hp, &lj);
+    if (acc) memcpy(&w[c * D], wp, sizeof(double) * D);
+    if (accepted_out) accepted_out[c] = acc;
+    if (nsteps_out) nsteps_out[c] = ns;
+    if (H_cur_out) H_cur_out[c] = Hc;
+    if (H_prop_out) H_prop_out[c] = Hp;
+    if (w_prop_out) memcpy(&w_prop_out[c * D], wp, sizeof(double) * D);
+    if (p_prop_out) memcpy(&p_prop_out[c * D], pp, sizeof(double) * D);
+    free(wp); free(pp); free(g);
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_hmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, uint64_t seed, int64_t chain_offset,
+                     const double *theta0, double *samples_out, int64_t *accept_out, int64_t *steps_out, double *seconds_out) {
+  NEED_DATA(ctx);
+  if (burn_in >= n_iter || burn_in < 0 || L < 1) return fail(ctx, RMHMC_ERR_INVALID, "need 0 <= burn_in < n_iter, L>=1");
+  const int D = ctx->D;
+  const int64_t S = n_iter - burn_in;
+  double t_post = 0;
+  int64_t *acc_all = (int64_t *)calloc(ctx->n, sizeof(int64_t));
+  for (int phase = 0; phase < 2; phase++) {  /* timer covers the post-burn-in transitions only (hmc.py:92-96) */
+    double t0 = now_s();
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t c = 0; c < ctx->n; c++) {
+      double *w = (double *)calloc(D, sizeof(double)), *wp = (double *)calloc(D, sizeof(double)), *pp = (double *)calloc(D, sizeof(double));
+      double *g = (double *)calloc(D, sizeof(double)), *z = (double *)calloc(D + 1, sizeof(double));
+      int64_t it0, it1, steps = 0;
+      if (phase == 0) {
+        for (int d = 0; d < D; d++) w[d] = theta0 ? theta0[c * D + d] : 0.0; /* hmc.py:27 */
+        it0 = 0; it1 = burn_in + 1;
+      } else {
+        memcpy(w, &samples_out[(c * S + 0) * D], sizeof(double) * D);
+        it0 = burn_in + 1; it1 = n_iter;
+      }
+      double ljl = log_joint(ctx, w);
+      for (int64_t it = it0; it < it1; it++) {
+        double u_len, g_dir, u_acc, Hc, Hp, lj; int ns;
+        rng_draws(seed, (uint64_t)(chain_offset + c), (uint32_t)it, D, z, &u_len, &g_dir, &u_acc);
+        if (hmc_transition(ctx, w, ljl, z, u_len, u_acc, L, eps, wp, pp, g, &ns, &Hc, &Hp, &lj)) {
+          memcpy(w, wp, sizeof(double) * D); ljl = lj; acc_all[c]++;
+        }
+        if (it >= burn_in) memcpy(&samples_out[(c * S + (it - burn_in)) * D], w, sizeof(double) * D);
+        if (it > burn_in) steps += ns;
+      }
+      if (steps_out && phase == 1) steps_out[c] = steps;
+      free(w); free(wp); free(pp); free(g); free(z);
+    }
+    if (phase == 1) t_post = now_s() - t0;
+  }
+  if (accept_out) memcpy(accept_out, acc_all, sizeof(int64_t) * ctx->n);
+  free(acc_all);
+  if (steps_out && n_iter == burn_in + 1)
+    for (int64_t c = 0; c < ctx->n; c++) steps_out[c] = 0;
+  if (seconds_out) *seconds_out = t_post;
+  return RMHMC_OK;
+}
+
 void rmhmc_destroy(rmhmc_ctx *ctx) {
   if (!ctx) return;
   if (ctx->chains) {

@@ -4,6 +4,7 @@ Host side of the C-ABI in include/rmhmc.h; mirrors the reference's
 ``code/rmhmc.py`` interface.  See DESIGN.md.
 """
 from .rmhmc import RMHMC  # noqa: F401
+from .hmc import HMC  # noqa: F401
 from . import tools, data  # noqa: F401
 
-__all__ = ["RMHMC", "tools", "data"]
+__all__ = ["RMHMC", "HMC", "tools", "data"]

@@ -45,6 +45,9 @@ SIGNATURES = {
     "rmhmc_chains_run": (C.c_int, [C.c_void_p, C.c_int64]),
     "rmhmc_chains_state": (C.c_int, [C.c_void_p, _dp, _lp, _lp]),
     "rmhmc_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _lp]),
+    "rmhmc_hmc_transition": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, _ip, _ip, _dp, _dp, _dp, _dp]),
+    "rmhmc_hmc_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_int64, _dp, _dp,
+                                   _lp, _lp, _dp]),
 }
 
 
@@ -184,6 +187,30 @@ class Context:
         self._ck(self.lib.rmhmc_sample(self._h, int(n_iter), int(burn_in), int(L), float(eps), int(K), int(seed),
                                        int(chain_offset), _ptr(th), _ptr(samples), _ptr(acc, _lp), _ptr(steps, _lp),
                                        C.cast(C.byref(secs), _dp)))
+        return samples, acc, steps, secs.value
+
+    # ---- plain HMC (code/hmc.py) ---------------------------------------------
+    def hmc_transition(self, w, z, u_len, u_acc, L=100, eps=0.14):
+        n, D = self.n, self.D
+        w = _f64(w, (n, D)).copy()
+        z = _f64(z, (n, D)); u_len = _f64(u_len, (n,)); u_acc = _f64(u_acc, (n,))
+        acc = np.zeros(n, dtype=np.int32); ns = np.zeros(n, dtype=np.int32)
+        Hc = np.empty(n); Hp = np.empty(n); wp = np.empty((n, D)); pp = np.empty((n, D))
+        self._ck(self.lib.rmhmc_hmc_transition(self._h, _ptr(w), _ptr(z), _ptr(u_len), _ptr(u_acc), int(L), float(eps),
+                                               _ptr(acc, _ip), _ptr(ns, _ip), _ptr(Hc), _ptr(Hp), _ptr(wp), _ptr(pp)))
+        return dict(w=w, accepted=acc, nsteps=ns, H_cur=Hc, H_prop=Hp, w_prop=wp, p_prop=pp)
+
+    def hmc_sample(self, n_iter, burn_in, L=100, eps=0.14, seed=0, chain_offset=0, theta0=None):
+        n, D = self.n, self.D
+        S = int(n_iter) - int(burn_in)
+        if S <= 0:
+            raise ValueError("BurnIn must be < NumOfIterations")
+        th = None if theta0 is None else _f64(np.broadcast_to(theta0, (n, D)))
+        samples = np.empty((n, S, D)); acc = np.zeros(n, dtype=np.int64); steps = np.zeros(n, dtype=np.int64)
+        secs = C.c_double(0.0)
+        self._ck(self.lib.rmhmc_hmc_sample(self._h, int(n_iter), int(burn_in), int(L), float(eps), int(seed),
+                                           int(chain_offset), _ptr(th), _ptr(samples), _ptr(acc, _lp), _ptr(steps, _lp),
+                                           C.cast(C.byref(secs), _dp)))
         return samples, acc, steps, secs.value
 
     def chains_init(self, theta0=None, seed=0, chain_offset=0, L=6, eps=0.5, K=4):

@@ -17,6 +17,12 @@
 #pragma once
 #include "kernels.hip.h"
 
+// No implicit a*b+c contraction in this file: the global-step loop of k_fused_small may be peeled or
+// versioned by the optimiser, and with fp-contract=fast the copies can round differently, which would make a
+// trajectory that continues in the next launch differ in the last bit from one that stays inside a launch
+// (observed: 1 ulp).  Every multiply-add that matters for speed is written as an explicit fma().
+#pragma clang fp contract(off)
+
 #define FS_D 8
 #define FS_T 36                  // packed lower triangle of an 8x8 matrix
 #define FS_WAVES 4
@@ -123,10 +129,45 @@ __device__ __forceinline__ void fs_pvc(double f, double& p, double& v, double& c
   v = __builtin_fma(-p, p, p);
   c = __builtin_fma(-2.0 * p, v, v);
 }
-template <int N>
-__device__ __forceinline__ void fs_allreduce(double (&v)[N]) {
+// Wave all-reduce of N values at once: a reduce-scatter over the top log2(P) lane bits (P = N rounded up to a
+// power of two; at every step a lane keeps one half of its list and sends the other half to lane^bit), plain
+// butterfly steps for the remaining lane bits, then a v_readlane broadcast.  P-1 + (6-log2 P) shuffles instead of
+// 6 N, and the totals come back wave-uniform.
+template <int LEN, int BIT>
+struct FsReduceScatter {
+  template <int P>
+  static __device__ __forceinline__ void run(double (&v)[P], int lane) {
+    constexpr int H = LEN / 2;
+    const bool up = (lane & BIT) != 0;
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+    for (int i = 0; i < H; ++i) {
+      const double send = up ? v[i] : v[i + H];
+      const double keep = up ? v[i + H] : v[i];
+      v[i] = keep + __shfl_xor(send, BIT, 64);
+    }
+    FsReduceScatter<H, BIT / 2>::run(v, lane);
+  }
+};
+template <int BIT>
+struct FsReduceScatter<1, BIT> {
+  template <int P>
+  static __device__ __forceinline__ void run(double (&v)[P], int) {
+#pragma unroll
+    for (int o = BIT; o >= 1; o >>= 1) v[0] += __shfl_xor(v[0], o, 64);  // remaining lane bits
+  }
+};
+template <int N>
+__device__ __forceinline__ void fs_allreduce(double (&v)[N], int lane) {
+  constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64;
+  static_assert(N <= 64, "at most 64 values");
+  constexpr int SH = P == 1 ? 6 : P == 2 ? 5 : P == 4 ? 4 : P == 8 ? 3 : P == 16 ? 2 : P == 32 ? 1 : 0;
+  double t[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) t[i] = (i < N) ? v[i] : 0.0;
+  FsReduceScatter<P, 32>::run(t, lane);
+  // value i now sits (fully summed) in the lanes whose top bits equal i
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = rdlane(t[0], i << SH);
 }
 
 // everything the sampler needs at a point (rmhmc.py:50-77 / :134-156), wave-uniform
@@ -146,6 +187,7 @@ __device__ __forceinline__ void fs_metric(const DevData& dd, const double* Xs, c
   double g[FS_D], lj = 0.0;
 #pragma unroll
   for (int d = 0; d < FS_D; ++d) g[d] = 0.0;
+#pragma unroll 2
   for (int n = lane; n < Mp; n += 64) {
     double x[FS_D];
     fs_load_row(Xs, Mp, n, x);
@@ -168,19 +210,28 @@ __device__ __forceinline__ void fs_metric(const DevData& dd, const double* Xs, c
       cbuf[n] = cn;
     }
   }
-  fs_allreduce(G);
-#pragma unroll
-  for (int a = 0; a < FS_D; ++a) G[FS_IDX(a, a)] += dd.inv_alpha;
   if (FULL) {
-    fs_allreduce(g);
-    lj = wave_sum(lj);
+    double red[FS_T + FS_D + 1];
+#pragma unroll
+    for (int t = 0; t < FS_T; ++t) red[t] = G[t];
+#pragma unroll
+    for (int d = 0; d < FS_D; ++d) red[FS_T + d] = g[d];
+    red[FS_T + FS_D] = lj;
+    fs_allreduce(red, lane);
+#pragma unroll
+    for (int t = 0; t < FS_T; ++t) G[t] = red[t];
+    lj = red[FS_T + FS_D];
 #pragma unroll
     for (int d = 0; d < FS_D; ++d) {
-      grad[d] = g[d] - w[d] * dd.inv_alpha;
+      grad[d] = red[FS_T + d] - w[d] * dd.inv_alpha;
       lj += (d < dd.D) ? (dd.log_prior_const - w[d] * w[d] * 0.5 * dd.inv_alpha) : 0.0;
     }
     ljl = lj;
+  } else {
+    fs_allreduce(G, lane);
   }
+#pragma unroll
+  for (int a = 0; a < FS_D; ++a) G[FS_IDX(a, a)] += dd.inv_alpha;
 }
 
 // u' dG/dw_d u = sum_n c_n (x_n.u)^2 x_nd with the cached c_n   (rmhmc.py:104-107,158-161)
@@ -188,6 +239,7 @@ __device__ __forceinline__ void fs_quad(const DevData& dd, const double* Xs, con
                                         double (&q)[FS_D]) {
 #pragma unroll
   for (int d = 0; d < FS_D; ++d) q[d] = 0.0;
+#pragma unroll 4
   for (int n = lane; n < dd.Mp; n += 64) {
     double x[FS_D];
     fs_load_row(Xs, dd.Mp, n, x);
@@ -196,7 +248,7 @@ __device__ __forceinline__ void fs_quad(const DevData& dd, const double* Xs, con
 #pragma unroll
     for (int d = 0; d < FS_D; ++d) q[d] = fma(r, x[d], q[d]);
   }
-  fs_allreduce(q);
+  fs_allreduce(q, lane);
 }
 
 // full record at pt.w
@@ -215,6 +267,7 @@ __device__ __forceinline__ int fs_eval_point(const DevData& dd, const double* Xs
   double tr[FS_D];
 #pragma unroll
   for (int d = 0; d < FS_D; ++d) tr[d] = 0.0;
+#pragma unroll 2
   for (int n = lane; n < dd.Mp; n += 64) {
     double x[FS_D], y[FS_D];
     fs_load_row(Xs, dd.Mp, n, x);
@@ -223,7 +276,7 @@ __device__ __forceinline__ int fs_eval_point(const DevData& dd, const double* Xs
 #pragma unroll
     for (int d = 0; d < FS_D; ++d) tr[d] = fma(ch, x[d], tr[d]);
   }
-  fs_allreduce(tr);
+  fs_allreduce(tr, lane);
 #pragma unroll
   for (int d = 0; d < FS_D; ++d) pt.tr[d] = tr[d];
   return bad;

@@ -100,7 +100,7 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 // The naive exp/log forms are kept on purpose: they overflow exactly where the reference does.
 // Accumulator register r of lane l holds data row (l>>4)+4r of the tile and chain l&15.
 // ---------------------------------------------------------------------------------------------
-enum { RP_V = 0, RP_F = 1 };
+enum { RP_V = 0, RP_F = 1, RP_G = 2 };  // RP_G: as RP_F without the v / c row vectors (plain HMC)
 
 template <int NB, int MODE>
 __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + n0];
     double xb[4][NB];
-    if (MODE == RP_F) {
+    if (MODE != RP_V) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
       } else {
         const double ef = exp(f);
         const double tn = dd.t[n];
-        if (live) {
+        if (MODE == RP_F && live) {
           out0[o] = v;
           out2[o] = v * (1.0 - 2.0 * p);
         }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
       }
     }
   }
-  if (MODE == RP_F) {
+  if (MODE != RP_V) {
     lj = col4_sum(lj);
     if (live && rr == 0) ljl_part[(size_t)cj * nsplit + split] = lj;
     if (live) {
@@ -852,6 +852,125 @@ __global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterP
 // trj -> cur for every chain (used after the initial point evaluation)
 __global__ __launch_bounds__(64) void k_commit_all(int D, int DP, Chains ch) {
   copy_rec(ch.cur, ch.trj, blockIdx.x, D, DP, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// plain HMC with identity mass (code/hmc.py:12-99): the separable special case, re-using the row pass
+// for the gradient and the log joint.  Records: cur/trj .w .grad .ljl only.
+// ---------------------------------------------------------------------------------------------
+// sum the row-split partials of k_rowpass<RP_G> into trj.grad / trj.ljl (hmc.py:53,61,64-67)
+__device__ __forceinline__ void hmc_finish_eval(const DevData& dd, const Chains& ch, int c, int lane, int nsplit) {
+  const int D = dd.D, DP = dd.DP;
+  const double wl = (lane < D) ? ch.trj.w[(size_t)c * DP + lane] : 0.0;
+  if (lane < D) {
+    double g = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) g += ch.gpart[((size_t)sp * ch.n + c) * DP + lane];
+    ch.trj.grad[(size_t)c * DP + lane] = g - wl * dd.inv_alpha;
+  }
+  double part = 0.0;
+  for (int b = lane; b < nsplit; b += 64) part += ch.ljl_part[(size_t)c * nsplit + b];
+  part += (lane < D) ? (dd.log_prior_const - wl * wl * 0.5 * dd.inv_alpha) : 0.0;
+  const double ljl = wave_sum(part);
+  if (lane == 0) ch.trj.ljl[c] = ljl;
+}
+__device__ __forceinline__ void hmc_copy(const Rec& dst, const Rec& src, int c, int D, int DP, int lane) {
+  if (lane < D) {
+    dst.w[(size_t)c * DP + lane] = src.w[(size_t)c * DP + lane];
+    dst.grad[(size_t)c * DP + lane] = src.grad[(size_t)c * DP + lane];
+  }
+  if (lane == 0) dst.ljl[c] = src.ljl[c];
+}
+// initial evaluation at theta0: trj -> cur
+__global__ __launch_bounds__(64) void k_hmc_init(DevData dd, Chains ch, int nsplit) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  hmc_finish_eval(dd, ch, c, lane, nsplit);
+  __syncthreads();
+  hmc_copy(ch.cur, ch.trj, c, dd.D, dd.DP, lane);
+}
+// start a transition (hmc.py:41-48,72)
+__global__ __launch_bounds__(64) void k_hmc_begin(int D, int DP, Chains ch, IterParams ip) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 0) return;
+  const long long it = ch.iter[c];
+  if (it >= ip.iter_limit) return;
+  hmc_copy(ch.trj, ch.cur, c, D, DP, lane);
+  double z = 0.0, u_len;
+  if (ip.z_in) {
+    z = (lane < D) ? ip.z_in[(size_t)c * D + lane] : 0.0;
+    u_len = ip.ulen_in[c];
+  } else {
+    const unsigned long long gid = (unsigned long long)(ip.chain_offset + c);
+    double U0, U1, Ua;
+    rng_block(ip.seed, gid, (uint32_t)it, (uint32_t)(lane >> 1), U0, U1);
+    const double R = sqrt(-2.0 * log(U0));
+    double sn, cs;
+    sincos(RM_PI2 * U1, &sn, &cs);
+    z = (lane < D) ? ((lane & 1) ? R * sn : R * cs) : 0.0;
+    rng_block(ip.seed, gid, (uint32_t)it, 0x40000000u, u_len, Ua);
+  }
+  const double kin = 0.5 * wave_sum(z * z);
+  if (lane < D) ch.p[(size_t)c * DP + lane] = z;  // Mass = I: p = z (hmc.py:41)
+  if (lane == 0) {
+    const int ns = (int)ceil(u_len * (double)ip.L);  // hmc.py:48
+    ch.steps_left[c] = ns;
+    ch.nsteps_last[c] = ns;
+    ch.Hcur[c] = -ch.cur.ljl[c] + kin;  // hmc.py:72
+    ch.status[c] = 0;
+    ch.phase[c] = (ns > 0) ? 1 : 2;
+  }
+}
+// first momentum half step and the position step (hmc.py:52-58); a NaN momentum ends the trajectory (:56-57)
+__global__ __launch_bounds__(64) void k_hmc_pre(int D, int DP, Chains ch, double eps) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  const size_t o = (size_t)c * DP + lane;
+  double p = 0.0;
+  if (lane < D) p = ch.p[o] + eps * 0.5 * ch.trj.grad[o];
+  const unsigned long long nan = __ballot(p != p);
+  if (lane < D) {
+    ch.p[o] = p;
+    if (!nan) ch.trj.w[o] += eps * p;
+  }
+  if (nan && lane == 0) { ch.status[c] |= 2; ch.steps_left[c] = 1; }
+}
+// gradient / log joint at the new position, second momentum half step (hmc.py:60-62)
+__global__ __launch_bounds__(64) void k_hmc_post(DevData dd, Chains ch, double eps, int nsplit) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  hmc_finish_eval(dd, ch, c, lane, nsplit);
+  __syncthreads();
+  const size_t o = (size_t)c * dd.DP + lane;
+  if (lane < dd.D && !(ch.status[c] & 2)) ch.p[o] += eps * 0.5 * ch.trj.grad[o];
+  if (lane == 0) { ch.steps_left[c] -= 1; ch.steps_done[c] += 1; }
+}
+// finish a transition (hmc.py:64-84)
+__global__ __launch_bounds__(64) void k_hmc_end(int D, int DP, Chains ch, IterParams ip) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int ph = ch.phase[c];
+  if (!(ph == 2 || (ph == 1 && ch.steps_left[c] == 0))) return;
+  const long long it = ch.iter[c];
+  const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
+  const double Hp = -ch.trj.ljl[c] + 0.5 * wave_sum(pl * pl);  // hmc.py:69
+  const double ratio = -Hp + ch.Hcur[c];
+  double u_acc;
+  if (ip.z_in) {
+    u_acc = ip.uacc_in[c];
+  } else {
+    double U0;
+    rng_block(ip.seed, (unsigned long long)(ip.chain_offset + c), (uint32_t)it, 0x40000000u, U0, u_acc);
+  }
+  const bool accept = (ratio > 0.0) || (ratio > log(u_acc));  // hmc.py:77
+  if (accept) hmc_copy(ch.cur, ch.trj, c, D, DP, lane);
+  __syncthreads();
+  if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S && lane < D)
+    ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + lane] = ch.cur.w[(size_t)c * DP + lane];
+  if (lane == 0) {
+    ch.Hprop[c] = Hp;
+    if (accept) ch.accepted[c] += 1;
+    ch.iter[c] = it + 1;
+    ch.phase[c] = 0;
+    if (it + 1 == ip.iter_limit && ip.done_count) atomicAdd(ip.done_count, 1);
+  }
 }
 
 // generic fills

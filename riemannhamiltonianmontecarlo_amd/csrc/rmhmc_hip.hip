@@ -57,6 +57,7 @@ struct rmhmc_ctx {
   std::vector<Group> groups;
   std::vector<void*> allocs;
   bool have_data = false, chains_ready = false;
+  int sampler = 0;           // 0: RMHMC (rmhmc.py), 1: plain HMC (hmc.py) -- selects the global step
   bool fused = false;        // small-problem path: D <= 8 and X fits in LDS (fused_small.hip.h)
   size_t fused_lds = 0;
   // sampler parameters of the stateful API
@@ -279,7 +280,20 @@ void launch_iter_end(rmhmc_ctx* ctx, const IterBase& b) {
   for (Group& g : ctx->groups) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_iter_end, ctx->D, ctx->DP, g.ch, ip); }
 }
 
+// plain HMC (hmc.py:38-84): begin / half step + position / gradient pass / half step / end
+void launch_hmc_global_step(rmhmc_ctx* ctx, const IterBase& b) {
+  std::vector<Phase> ph;
+  const double eps = ctx->eps;
+  ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_hmc_begin, ctx->D, ctx->DP, g.ch, ip); });
+  ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_hmc_pre, ctx->D, ctx->DP, g.ch, eps); });
+  ph.push_back([ctx](Group& g) { launch_rowpass<RP_G>(ctx, g, g.ch.trj.w, nullptr); });
+  ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_hmc_post, ctx->dd, g.ch, eps, g.nsplit); });
+  ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_hmc_end, ctx->D, ctx->DP, g.ch, ip); });
+  run_phases(ctx, ph);
+}
+
 void launch_global_step(rmhmc_ctx* ctx, const IterBase& b) {
+  if (ctx->sampler == 1) { launch_hmc_global_step(ctx, b); return; }
   std::vector<Phase> ph;
   ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_iter_begin, ctx->D, ctx->DP, g.ch, ip); });
   step_phases(ctx, ph);
@@ -681,7 +695,7 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
   long long s = 0;
   const int poll = 4;
   fork_streams(ctx);
-  if (ctx->fused) {  // one launch for the guaranteed part, then short launches until every chain is done
+  if (ctx->fused && ctx->sampler == 0) {  // one launch for the guaranteed part, then short launches until every chain is done
     launch_fused(ctx, ib, min_steps);
     s = min_steps;
     for (;;) {
@@ -751,6 +765,100 @@ int rmhmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, dou
     return RMHMC_OK;
   }();
   (void)hipFree(d_samples);
+  return rc;
+}
+
+// ---- plain HMC (code/hmc.py) -------------------------------------------------------------------------
+// evaluate gradient and log joint at theta0 and commit them as the current point of every chain
+static int hmc_init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] or NULL: zeros, hmc.py:27 */) {
+  std::vector<double> th;
+  if (!theta0_host) { th.assign((size_t)ctx->n * ctx->D, 0.0); theta0_host = th.data(); }
+  RC(upload_vec(ctx, ctx->ch.trj.w, theta0_host));
+  fill_int(ctx, ctx->ch.phase, 1, ctx->n);
+  fork_streams(ctx);
+  for (Group& g : ctx->groups) launch_rowpass<RP_G>(ctx, g, g.ch.trj.w, nullptr);
+  for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_hmc_init, ctx->dd, g.ch, g.nsplit);
+  join_streams(ctx);
+  fill_int(ctx, ctx->ch.phase, 0, ctx->n);
+  fill_int(ctx, ctx->ch.steps_left, 0, ctx->n);
+  fill_int(ctx, ctx->ch.status, 0, ctx->n);
+  fill_ll(ctx, ctx->ch.iter, 0, ctx->n);
+  fill_ll(ctx, ctx->ch.accepted, 0, ctx->n);
+  fill_ll(ctx, ctx->ch.steps_done, 0, ctx->n);
+  HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+  return sync(ctx);
+}
+
+int rmhmc_hmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u_len, const double* u_acc, int32_t L, double eps,
+                         int32_t* accepted_out, int32_t* nsteps_out, double* H_cur_out, double* H_prop_out, double* w_prop_out,
+                         double* p_prop_out) {
+  NEED_DATA(ctx);
+  if (!w || !z || !u_len || !u_acc || L < 1) return fail(ctx, RMHMC_ERR_INVALID, "hmc_transition: null pointer or L < 1");
+  ctx->chains_ready = false;
+  ctx->L = L; ctx->eps = eps; ctx->sampler = 1;
+  int rc = [&]() -> int {
+    RC(hmc_init_chains(ctx, w));
+    RC(upload(ctx, ctx->d_z, z, (size_t)ctx->n * ctx->D));
+    RC(upload(ctx, ctx->d_ulen, u_len, ctx->n));
+    RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
+    const IterBase ib{1, 0, 0, nullptr, true, false};
+    fork_streams(ctx);
+    for (int s = 0; s < L; ++s) launch_hmc_global_step(ctx, ib);
+    join_streams(ctx);
+    std::vector<long long> acc(ctx->n);
+    RC(download_vec(ctx, w, ctx->ch.cur.w));
+    RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
+    if (nsteps_out) RC(download(ctx, nsteps_out, ctx->ch.nsteps_last, ctx->n));
+    if (H_cur_out) RC(download(ctx, H_cur_out, ctx->ch.Hcur, ctx->n));
+    if (H_prop_out) RC(download(ctx, H_prop_out, ctx->ch.Hprop, ctx->n));
+    if (w_prop_out) RC(download_vec(ctx, w_prop_out, ctx->ch.trj.w));
+    if (p_prop_out) RC(download_vec(ctx, p_prop_out, ctx->ch.p));
+    RC(sync(ctx));
+    if (accepted_out) for (int64_t c = 0; c < ctx->n; ++c) accepted_out[c] = (int32_t)acc[c];
+    return RMHMC_OK;
+  }();
+  ctx->sampler = 0;
+  return rc;
+}
+
+int rmhmc_hmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, uint64_t seed, int64_t chain_offset,
+                     const double* theta0, double* samples_out, int64_t* accept_out, int64_t* steps_out, double* seconds_out) {
+  NEED_DATA(ctx);
+  if (!samples_out || burn_in < 0 || burn_in >= n_iter || L < 1)
+    return fail(ctx, RMHMC_ERR_INVALID, "hmc_sample: need samples_out, 0 <= burn_in < n_iter, L >= 1");
+  ctx->chains_ready = false;
+  ctx->L = L; ctx->eps = eps; ctx->seed = seed; ctx->chain_offset = chain_offset; ctx->sampler = 1;
+  const long long S = n_iter - burn_in;
+  double* d_samples = nullptr;
+  HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
+  int rc = [&]() -> int {
+    RC(hmc_init_chains(ctx, theta0));
+    const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
+    RC(run_until_done(ctx, ipA, burn_in + 1));
+    HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+    RC(sync(ctx));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_iter > burn_in + 1) {
+      const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
+      RC(run_until_done(ctx, ipB, n_iter - burn_in - 1));
+    }
+    RC(sync(ctx));
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<long long> a(ctx->n), s1(ctx->n), s0(ctx->n);
+    RC(download(ctx, a.data(), ctx->ch.accepted, ctx->n));
+    RC(download(ctx, s1.data(), ctx->ch.steps_done, ctx->n));
+    RC(download(ctx, s0.data(), ctx->d_steps0, ctx->n));
+    RC(sync(ctx));
+    for (int64_t c = 0; c < ctx->n; ++c) {
+      if (accept_out) accept_out[c] = a[c];
+      if (steps_out) steps_out[c] = s1[c] - s0[c];
+    }
+    return RMHMC_OK;
+  }();
+  (void)hipFree(d_samples);
+  ctx->sampler = 0;
   return rc;
 }
 
