@@ -99,10 +99,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the multi-rank logic on fewer GPUs than ranks
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)
+    ddev = torch.device("cuda", dev) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -116,7 +123,7 @@ def main():
     flags = _capi.COMPAT if args.compat else 0
 
     lib = _capi.load_hip_library()  # raises if the extension is not built
-    ctx = lib.context(M, D, n, flags=flags, device=local_rank)
+    ctx = lib.context(M, D, n, flags=flags, device=dev)
     ctx.set_data(XX, t)
     ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
 
@@ -136,7 +143,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=ddev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -148,7 +155,7 @@ def main():
 
     if world > 1:
         # the one exchange of the sharded path: gather the chain positions at write-out (RCCL over xGMI)
-        wt = torch.from_numpy(w_end).cuda()
+        wt = torch.from_numpy(w_end).to(ddev)
         gathered = [torch.empty_like(wt) for _ in range(world)] if rank == 0 else None
         dist.gather(wt, gathered, dst=0)
         if rank == 0:
