@@ -166,16 +166,20 @@ def main():
         # second half of the metric: sum over chains of (min over dims of the per-chain ESS) / seconds of the
         # post-burn-in phase (TimeTaken semantics, rmhmc.py:194-198).  ESS by tools.CalculateESS semantics with
         # the MATLAB FFT length (no wrap-around); estimated on a subset of chains to bound the host FFT work.
-        from riemannhamiltonianmontecarlo_amd import tools
         burn = 100
-        smp, acc_s, steps_s, secs = ctx.sample(burn + args.ess_iters, burn, L=L, eps=eps, K=K, seed=7, chain_offset=rank * n)
-        sub = smp[:: max(1, n // 256)]
-        me = tools.min_ess_per_chain(sub, nfft="matlab")
-        ess = {"min_ess_per_sec": float(me.mean() * n * world / secs), "seconds": secs, "post_burn_in_transitions": args.ess_iters,
-               "mean_min_ess_per_chain": float(me.mean()), "chains_used_for_estimate": int(sub.shape[0]),
-               "leapfrog_steps_per_sec_during_sampling": float(steps_s.sum() * world / secs),
-               "acceptance": float(acc_s.sum()) / float((burn + args.ess_iters) * n),
-               "note": "per-chain ESS (MATLAB CalculateStatistics.m semantics), summed over chains; rank-0 shard scaled by world size"}
+        st = ctx.sample_stats(burn + args.ess_iters, burn, L=L, eps=eps, K=K, seed=7, chain_offset=rank * n)
+        me = np.nanmin(st["ess"], axis=1)                       # per chain: min over dimensions
+        tot = float(np.nansum(me)); secs = st["seconds"]; lsteps = float(st["leapfrog_steps"].sum()); acc_n = float(st["accepted"].sum())
+        if world > 1:
+            tt = torch.tensor([tot, lsteps, acc_n], device=ddev, dtype=torch.float64); dist.all_reduce(tt)
+            ts = torch.tensor([secs], device=ddev, dtype=torch.float64); dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            tot, lsteps, acc_n, secs = float(tt[0]), float(tt[1]), float(tt[2]), float(ts[0])
+        ess = {"min_ess_per_sec": tot / secs, "seconds": secs, "post_burn_in_transitions": args.ess_iters,
+               "mean_min_ess_per_chain": tot / (n * world), "chains": n * world,
+               "leapfrog_steps_per_sec_during_sampling": lsteps / secs,
+               "acceptance": acc_n / float((burn + args.ess_iters) * n * world),
+               "note": "per-chain ESS (MATLAB CalculateStatistics.m semantics: ESS per chain, min over dimensions), summed over "
+                       "all chains; computed on the device by rmhmc_sample_stats (no sample transfer)"}
 
     if rank == 0:
         total_steps = world * n * args.steps

@@ -180,6 +180,25 @@ int rmhmc_hmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L,
                      double *samples_out, int64_t *accept_out, int64_t *steps_out,
                      double *seconds_out);
 
+/* ---- widening, SURVEY.md 8(f)-2: the min-ESS half of the metric on the device ------------------------
+ * Geyer initial-monotone-sequence ESS with the semantics of tools.CalculateESS(Samples, MaxLag = S-1)
+ * (code/tools.py:32-74; authors_code/.../Results/CalculateESS.m), computed directly (autocovariances lag by
+ * lag until the pair sum turns non-positive) instead of through an FFT of all lags: identical to the MATLAB
+ * original (2^(k+1)-point FFT, ac.m:78) and to the Python translation wherever its 8193-point FFT does not
+ * wrap around (lags < nFFT - S).                                                                      */
+
+/* samples[n*S*P] (host, chain-major, row s = sample s) -> ess_out[n*P].  n here is any number of sample
+ * blocks (it need not equal the context's n_chains).  S <= 20000.                                      */
+int rmhmc_ess(rmhmc_ctx *ctx, const double *samples, int64_t n, int64_t S, int32_t P, double *ess_out);
+
+/* rmhmc_sample without the sample transfer: per-chain posterior mean / population variance / ESS of every
+ * dimension over the S = n_iter-burn_in saved states, reduced on the device (config 4 at S = 5000 would be
+ * 168 GB of raw samples).  mean_out, var_out, ess_out: [n*D], each optional.                            */
+int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K,
+                       uint64_t seed, int64_t chain_offset, const double *theta0, double *mean_out,
+                       double *var_out, double *ess_out, int64_t *accept_out, int64_t *steps_out,
+                       double *seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -927,6 +927,69 @@ int rmhmc_hmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L,
   return RMHMC_OK;
 }
 
+/* ------------------------------------------------------------------------ */
+/* ESS: restatement of tools.CalculateESS (tools.py:32-74) without the FFT    */
+/* ------------------------------------------------------------------------ */
+/* series x[s*stride], s < S.  Autocovariances are computed lag by lag (the FFT of tools.ac, tools.py:21-30,
+ * yields the same sums for every lag it does not wrap); Gamma_j = rho_2j + rho_2j+1 (tools.py:46-50), running
+ * minimum (:54-60), sum of the positive prefix (:62-67), floor at 1 (:70-71), ESS = S / MonoEst (:73). */
+static void ess_series(const double *x, int64_t S, int64_t stride, double *ess, double *mean_out, double *var_out) {
+  double m = 0;
+  for (int64_t s = 0; s < S; s++) m += x[s * stride];
+  m /= (double)S;
+  double *xc = (double *)malloc(sizeof(double) * S);
+  double c0 = 0;
+  for (int64_t s = 0; s < S; s++) { xc[s] = x[s * stride] - m; c0 += xc[s] * xc[s]; }
+  if (mean_out) *mean_out = m;
+  if (var_out) *var_out = c0 / (double)S;
+  double prev = INFINITY, sum = 0;
+  const int64_t half = S / 2; /* floor((MaxLag+1)/2) with MaxLag = S-1 */
+  for (int64_t j = 0; j < half; j++) {
+    double a = 0, b = 0;
+    for (int64_t s = 0; s + 2 * j < S; s++) a += xc[s] * xc[s + 2 * j];
+    for (int64_t s = 0; s + 2 * j + 1 < S; s++) b += xc[s] * xc[s + 2 * j + 1];
+    double g = (a + b) / c0;
+    if (g > prev) g = prev;
+    if (!(g > 0)) break;
+    sum += g; prev = g;
+  }
+  double mono = -1.0 + 2.0 * sum;
+  if (mono < 1) mono = 1;
+  *ess = (c0 > 0) ? (double)S / mono : NAN;
+  free(xc);
+}
+
+int rmhmc_ess(rmhmc_ctx *ctx, const double *samples, int64_t n, int64_t S, int32_t P, double *ess_out) {
+  if (!ctx || !samples || !ess_out || n < 1 || S < 2 || P < 1) return fail(ctx, RMHMC_ERR_INVALID, "ess: bad argument");
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t i = 0; i < n * P; i++) ess_series(&samples[(i / P) * S * P + (i % P)], S, P, &ess_out[i], NULL, NULL);
+  return RMHMC_OK;
+}
+
+int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                       int64_t chain_offset, const double *theta0, double *mean_out, double *var_out, double *ess_out,
+                       int64_t *accept_out, int64_t *steps_out, double *seconds_out) {
+  NEED_DATA(ctx);
+  if (burn_in >= n_iter || burn_in < 0) return fail(ctx, RMHMC_ERR_INVALID, "need 0 <= burn_in < n_iter");
+  const int64_t S = n_iter - burn_in;
+  const int D = ctx->D;
+  double *smp = (double *)malloc(sizeof(double) * ctx->n * S * D);
+  int rc = rmhmc_sample(ctx, n_iter, burn_in, L, eps, K, seed, chain_offset, theta0, smp, accept_out, steps_out, seconds_out);
+  if (rc == RMHMC_OK) {
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t i = 0; i < ctx->n * D; i++) {
+      double e, m, v;
+      if (S >= 2) ess_series(&smp[(i / D) * S * D + (i % D)], S, D, &e, &m, &v);
+      else { m = smp[i]; v = 0; e = NAN; }
+      if (ess_out) ess_out[i] = e;
+      if (mean_out) mean_out[i] = m;
+      if (var_out) var_out[i] = v;
+    }
+  }
+  free(smp);
+  return rc;
+}
+
 void rmhmc_destroy(rmhmc_ctx *ctx) {
   if (!ctx) return;
   if (ctx->chains) {

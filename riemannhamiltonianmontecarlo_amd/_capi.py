@@ -45,6 +45,9 @@ SIGNATURES = {
     "rmhmc_chains_run": (C.c_int, [C.c_void_p, C.c_int64]),
     "rmhmc_chains_state": (C.c_int, [C.c_void_p, _dp, _lp, _lp]),
     "rmhmc_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _lp]),
+    "rmhmc_ess": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64, C.c_int32, _dp]),
+    "rmhmc_sample_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
+                                     _dp, _dp, _dp, _dp, _lp, _lp, _dp]),
     "rmhmc_hmc_transition": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, _ip, _ip, _dp, _dp, _dp, _dp]),
     "rmhmc_hmc_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_int64, _dp, _dp,
                                    _lp, _lp, _dp]),
@@ -188,6 +191,29 @@ class Context:
                                        int(chain_offset), _ptr(th), _ptr(samples), _ptr(acc, _lp), _ptr(steps, _lp),
                                        C.cast(C.byref(secs), _dp)))
         return samples, acc, steps, secs.value
+
+    # ---- ESS on the device (tools.py:32-74) -----------------------------------
+    def ess(self, samples):
+        samples = _f64(samples)
+        if samples.ndim == 2:
+            samples = samples[None]
+        n, S, P = samples.shape
+        out = np.empty((n, P))
+        self._ck(self.lib.rmhmc_ess(self._h, _ptr(samples), n, S, P, _ptr(out)))
+        return out
+
+    def sample_stats(self, n_iter, burn_in, L=6, eps=0.5, K=4, seed=0, chain_offset=0, theta0=None):
+        n, D = self.n, self.D
+        if int(n_iter) - int(burn_in) <= 0:
+            raise ValueError("BurnIn must be < NumOfIterations")
+        th = None if theta0 is None else _f64(np.broadcast_to(theta0, (n, D)))
+        mean = np.empty((n, D)); var = np.empty((n, D)); ess = np.empty((n, D))
+        acc = np.zeros(n, dtype=np.int64); steps = np.zeros(n, dtype=np.int64)
+        secs = C.c_double(0.0)
+        self._ck(self.lib.rmhmc_sample_stats(self._h, int(n_iter), int(burn_in), int(L), float(eps), int(K), int(seed),
+                                             int(chain_offset), _ptr(th), _ptr(mean), _ptr(var), _ptr(ess), _ptr(acc, _lp),
+                                             _ptr(steps, _lp), C.cast(C.byref(secs), _dp)))
+        return dict(mean=mean, var=var, ess=ess, accepted=acc, leapfrog_steps=steps, seconds=secs.value)
 
     # ---- plain HMC (code/hmc.py) ---------------------------------------------
     def hmc_transition(self, w, z, u_len, u_acc, L=100, eps=0.14):

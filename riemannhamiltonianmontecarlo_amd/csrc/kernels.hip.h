@@ -973,6 +973,53 @@ __global__ __launch_bounds__(64) void k_hmc_end(int D, int DP, Chains ch, IterPa
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ESS on the device (widening row 8f-2): tools.CalculateESS(Samples, S-1), tools.py:32-74, for one series per
+// wavefront.  samples[(c*S + s)*P + d]; the centred series lives in LDS; autocovariances are evaluated lag by lag
+// (two per Geyer pair, tools.py:46-50) until the running-minimum pair sum (:54-60) turns non-positive, which is
+// where the reference's "sum of the positive Gammas" (:62-67) ends.  Also returns mean and population variance.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ess(const double* __restrict__ samples, long long S, int P, double* __restrict__ ess_out,
+                                            double* __restrict__ mean_out, double* __restrict__ var_out) {
+  extern __shared__ __attribute__((aligned(16))) double ess_x[];
+  const long long idx = blockIdx.x;
+  const long long c = idx / P;
+  const int d = (int)(idx % P);
+  const int lane = threadIdx.x;
+  const double* __restrict__ x = samples + (size_t)c * S * P + d;
+  double m = 0.0;
+  for (long long s = lane; s < S; s += 64) m += x[(size_t)s * P];
+  m = wave_sum(m) / (double)S;
+  double c0 = 0.0;
+  for (long long s = lane; s < S; s += 64) {
+    const double v = x[(size_t)s * P] - m;
+    ess_x[s] = v;
+    c0 = fma(v, v, c0);
+  }
+  c0 = wave_sum(c0);
+  __syncthreads();
+  double prev = INFINITY, sum = 0.0;
+  const long long half = S / 2;
+  for (long long j = 0; j < half; ++j) {
+    const long long l0 = 2 * j, l1 = 2 * j + 1;
+    double a = 0.0, b = 0.0;
+    for (long long s = lane; s + l0 < S; s += 64) a = fma(ess_x[s], ess_x[s + l0], a);
+    for (long long s = lane; s + l1 < S; s += 64) b = fma(ess_x[s], ess_x[s + l1], b);
+    double g = wave_sum(a + b) / c0;
+    if (g > prev) g = prev;
+    if (!(g > 0.0)) break;
+    sum += g;
+    prev = g;
+  }
+  double mono = -1.0 + 2.0 * sum;
+  if (mono < 1.0) mono = 1.0;
+  if (lane == 0) {
+    if (ess_out) ess_out[idx] = (c0 > 0.0) ? (double)S / mono : NAN;
+    if (mean_out) mean_out[idx] = m;
+    if (var_out) var_out[idx] = c0 / (double)S;
+  }
+}
+
 // generic fills
 __global__ void k_fill_int(int* p, int v, size_t n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

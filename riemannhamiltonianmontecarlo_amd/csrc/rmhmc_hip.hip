@@ -724,6 +724,41 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
   return RMHMC_OK;
 }
 
+// Runs the sampler and leaves the saved states in a freshly allocated device buffer *d_samples_out
+// ([n][S][D]); the caller frees it.
+static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const double* theta0, double** d_samples_out,
+                       int64_t* accept_out, int64_t* steps_out, double* seconds_out) {
+  const long long S = n_iter - burn_in;
+  double* d_samples = nullptr;
+  HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
+  *d_samples_out = d_samples;
+  RC(init_chains(ctx, theta0));
+  // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
+  // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
+  const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
+  RC(run_until_done(ctx, ipA, burn_in + 1));
+  HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+  RC(sync(ctx));
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n_iter > burn_in + 1) {
+    const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
+    RC(run_until_done(ctx, ipB, n_iter - burn_in - 1));
+  }
+  RC(sync(ctx));
+  if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::vector<long long> a(ctx->n), s1(ctx->n), s0(ctx->n);
+  RC(download(ctx, a.data(), ctx->ch.accepted, ctx->n));
+  RC(download(ctx, s1.data(), ctx->ch.steps_done, ctx->n));
+  RC(download(ctx, s0.data(), ctx->d_steps0, ctx->n));
+  RC(sync(ctx));
+  for (int64_t c = 0; c < ctx->n; ++c) {
+    if (accept_out) accept_out[c] = a[c];
+    if (steps_out) steps_out[c] = s1[c] - s0[c];
+  }
+  return RMHMC_OK;
+}
+
 int rmhmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
                  int64_t chain_offset, const double* theta0, double* samples_out, int64_t* accept_out, int64_t* steps_out,
                  double* seconds_out) {
@@ -732,39 +767,69 @@ int rmhmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, dou
     return fail(ctx, RMHMC_ERR_INVALID, "sample: need samples_out, 0 <= burn_in < n_iter, L >= 1, K >= 1");
   ctx->chains_ready = false;
   ctx->L = L; ctx->eps = eps; ctx->K = K; ctx->seed = seed; ctx->chain_offset = chain_offset;
+  double* d_samples = nullptr;
+  int rc = sample_core(ctx, n_iter, burn_in, theta0, &d_samples, accept_out, steps_out, seconds_out);
+  if (rc == RMHMC_OK) {
+    rc = [&]() -> int {
+      HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * (size_t)ctx->n * (n_iter - burn_in) * ctx->D, hipMemcpyDeviceToHost, ctx->stream));
+      return sync(ctx);
+    }();
+  }
+  if (d_samples) (void)hipFree(d_samples);
+  return rc;
+}
+
+// ---- ESS / posterior summaries on the device (tools.py:32-74) -------------------------------------------
+static int launch_ess(rmhmc_ctx* ctx, const double* d_samples, long long nblocks, long long S, int P, double* d_ess, double* d_mean, double* d_var) {
+  if (S < 2 || S > 20000) return fail(ctx, RMHMC_ERR_UNSUPPORTED, "ess: 2 <= S <= 20000 samples per chain (the centred series is held in LDS)");
+  static bool attr_set = false;
+  if (!attr_set) { HIPCK(hipFuncSetAttribute((const void*)k_ess, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+  hipLaunchKernelGGL(k_ess, dim3((unsigned)(nblocks * P)), dim3(64), (size_t)S * sizeof(double), ctx->stream, d_samples, S, P, d_ess, d_mean, d_var);
+  return RMHMC_OK;
+}
+
+int rmhmc_ess(rmhmc_ctx* ctx, const double* samples, int64_t n, int64_t S, int32_t P, double* ess_out) {
+  if (!ctx || !samples || !ess_out || n < 1 || P < 1 || n * (int64_t)P > 0x7fffffffLL) return fail(ctx, RMHMC_ERR_INVALID, "ess: bad argument");
+  HIPCK(hipSetDevice(ctx->device));
+  double *d_s = nullptr, *d_e = nullptr;
+  HIPCK(hipMalloc((void**)&d_s, sizeof(double) * (size_t)n * S * P));
+  int rc = [&]() -> int {
+    HIPCK(hipMalloc((void**)&d_e, sizeof(double) * (size_t)n * P));
+    HIPCK(hipMemcpyAsync(d_s, samples, sizeof(double) * (size_t)n * S * P, hipMemcpyHostToDevice, ctx->stream));
+    RC(launch_ess(ctx, d_s, n, S, P, d_e, nullptr, nullptr));
+    HIPCK(hipMemcpyAsync(ess_out, d_e, sizeof(double) * (size_t)n * P, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+  }();
+  (void)hipFree(d_s);
+  if (d_e) (void)hipFree(d_e);
+  return rc;
+}
+
+int rmhmc_sample_stats(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                       int64_t chain_offset, const double* theta0, double* mean_out, double* var_out, double* ess_out,
+                       int64_t* accept_out, int64_t* steps_out, double* seconds_out) {
+  NEED_DATA(ctx);
+  if (burn_in < 0 || burn_in >= n_iter || L < 1 || K < 1)
+    return fail(ctx, RMHMC_ERR_INVALID, "sample_stats: need 0 <= burn_in < n_iter, L >= 1, K >= 1");
+  ctx->chains_ready = false;
+  ctx->L = L; ctx->eps = eps; ctx->K = K; ctx->seed = seed; ctx->chain_offset = chain_offset;
   const long long S = n_iter - burn_in;
   double* d_samples = nullptr;
-  HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
-  int rc = [&]() -> int {
-    RC(init_chains(ctx, theta0));
-    // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
-    // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
-    const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
-    RC(run_until_done(ctx, ipA, burn_in + 1));
-    HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
-    RC(sync(ctx));
-    const auto t0 = std::chrono::steady_clock::now();
-    if (n_iter > burn_in + 1) {
-      const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
-      RC(run_until_done(ctx, ipB, n_iter - burn_in - 1));
-    }
-    RC(sync(ctx));
-    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (seconds_out) *seconds_out = secs;
-    HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D, hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<long long> a(ctx->n), s1(ctx->n), s0(ctx->n);
-    RC(download(ctx, a.data(), ctx->ch.accepted, ctx->n));
-    RC(download(ctx, s1.data(), ctx->ch.steps_done, ctx->n));
-    RC(download(ctx, s0.data(), ctx->d_steps0, ctx->n));
-    RC(sync(ctx));
-    for (int64_t c = 0; c < ctx->n; ++c) {
-      if (accept_out) accept_out[c] = a[c];
-      if (steps_out) steps_out[c] = s1[c] - s0[c];
-    }
-    return RMHMC_OK;
-  }();
-  (void)hipFree(d_samples);
+  double* d_out = nullptr;  // [3][n][D]: ess, mean, var
+  int rc = sample_core(ctx, n_iter, burn_in, theta0, &d_samples, accept_out, steps_out, seconds_out);
+  if (rc == RMHMC_OK) {
+    rc = [&]() -> int {
+      const size_t nd = (size_t)ctx->n * ctx->D;
+      HIPCK(hipMalloc((void**)&d_out, sizeof(double) * 3 * nd));
+      RC(launch_ess(ctx, d_samples, ctx->n, S, ctx->D, d_out, d_out + nd, d_out + 2 * nd));
+      if (ess_out) RC(download(ctx, ess_out, d_out, nd));
+      if (mean_out) RC(download(ctx, mean_out, d_out + nd, nd));
+      if (var_out) RC(download(ctx, var_out, d_out + 2 * nd, nd));
+      return sync(ctx);
+    }();
+  }
+  if (d_samples) (void)hipFree(d_samples);
+  if (d_out) (void)hipFree(d_out);
   return rc;
 }
 

@@ -12,7 +12,6 @@ import os
 import numpy as np
 
 from . import _capi
-from . import tools
 
 
 def shard_range(n_total, world, rank):
@@ -67,14 +66,23 @@ def sample_sharded(XX, t, n_chains, NumOfIterations=6000, BurnIn=1000, NumOfLeap
     counts = [shard_range(n_chains, world, r)[1] - shard_range(n_chains, world, r)[0] for r in range(world)]
     n_local = end - start
     S = NumOfIterations - BurnIn
+    summ = None
     if n_local > 0:
         th = None if theta0 is None else np.broadcast_to(theta0, (n_chains, D))[start:end]
         with lib.context(N, D, n_local, flags=_capi.COMPAT if compat else 0, device=local_rank if backend == "nccl" else 0) as ctx:
             ctx.set_data(XX, t, alpha)
-            smp, acc, steps, secs = ctx.sample(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps,
-                                               seed=seed, chain_offset=start, theta0=th)
+            if gather == "samples":
+                smp, acc, steps, secs = ctx.sample(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps,
+                                                   seed=seed, chain_offset=start, theta0=th)
+            else:  # reduced on the device: no sample transfer at all (rmhmc_sample_stats)
+                st = ctx.sample_stats(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps, seed=seed,
+                                      chain_offset=start, theta0=th)
+                acc, steps, secs = st["accepted"], st["leapfrog_steps"], st["seconds"]
+                summ = np.concatenate([st["mean"], st["var"], np.nanmin(st["ess"], axis=1, keepdims=True)], axis=1)
+                smp = np.zeros((n_local, 0, D))
     else:
         smp = np.zeros((0, S, D)); acc = np.zeros(0, dtype=np.int64); steps = np.zeros(0, dtype=np.int64); secs = 0.0
+        summ = np.zeros((0, 2 * D + 1))
     # timing: the job is as slow as its slowest rank
     tt = torch.tensor([secs], dtype=torch.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -84,8 +92,6 @@ def sample_sharded(XX, t, n_chains, NumOfIterations=6000, BurnIn=1000, NumOfLeap
     if gather == "samples":
         payload = _gather_rows(smp, counts, device)
     else:
-        summ = np.concatenate([smp.mean(axis=1), smp.var(axis=1),
-                               tools.min_ess_per_chain(smp).reshape(-1, 1) if S > 3 else np.zeros((n_local, 1))], axis=1)
         g = _gather_rows(summ, counts, device)
         payload = None if g is None else dict(mean=g[:, :D], var=g[:, D:2 * D], min_ess=g[:, 2 * D])
     if rank != 0:

@@ -351,3 +351,28 @@ def test_hmc_sampler_matches_oracle_and_shim(hip, oracle):
         w0 = np.zeros((2, D)); w0[1] = 300.0
         r = ctx.hmc_transition(w0, np.ones((2, D)), np.full(2, 0.5), np.full(2, 0.5), L=10, eps=0.5)
         assert np.array_equal(r["w"][1], w0[1]) and np.isfinite(r["w"]).all()
+
+
+# ---- widening row 8(f)-2: ESS on the device (code/tools.py:32-74) ---------------------------------------------------
+def test_device_ess_matches_reference_and_host(hip, oracle):
+    import os
+    from conftest import GOLDEN
+    from riemannhamiltonianmontecarlo_amd import tools
+    rs = np.random.RandomState(4)
+    with hip.context(10, 2, 1) as ctx:
+        for name in ("ess_ar1", "ess_pima_chain"):
+            g = np.load(os.path.join(GOLDEN, name + ".npz"))
+            assert np.allclose(ctx.ess(g["samples"])[0], g["ess"], rtol=1e-9), name
+        x = np.cumsum(rs.randn(5, 777, 6), axis=1) * 0.05 + rs.randn(5, 777, 6)
+        ref = np.stack([tools.CalculateESS(x[i], 776, nfft="matlab").ravel() for i in range(5)])
+        assert np.allclose(ctx.ess(x), ref, rtol=1e-9)
+        big = rs.randn(2, 12000, 3)                      # longer than the default 64 KB of LDS
+        ref = np.stack([tools.CalculateESS(big[i], 11999, nfft="matlab").ravel() for i in range(2)])
+        assert np.allclose(ctx.ess(big), ref, rtol=1e-9)
+
+    def fn(ctx):
+        return ctx.sample_stats(30, 8, L=3, seed=6)
+
+    a, b = _both(hip, oracle, 300, 12, 7, fn)
+    assert np.array_equal(a["accepted"], b["accepted"]) and np.array_equal(a["leapfrog_steps"], b["leapfrog_steps"])
+    assert rel_err(a["mean"], b["mean"]) < 1e-7 and rel_err(a["var"], b["var"]) < 1e-6 and rel_err(a["ess"], b["ess"]) < 1e-5

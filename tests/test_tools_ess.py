@@ -38,3 +38,25 @@ def test_lognormpdf():
     w = np.array([[0.1], [-0.2], [0.3]])
     v = tools.LogNormPDF(np.zeros((1, 3)), w, 100.0)
     assert abs(v - np.sum(-0.5 * np.log(2 * np.pi * 100) - w ** 2 / 200)) < 1e-14
+
+
+def test_oracle_direct_ess_matches_reference(oracle):
+    """rmhmc_ess / rmhmc_sample_stats of the C-ABI (direct lag-by-lag evaluation, no FFT) against the outputs of the
+    reference's tools.CalculateESS (golden) and against the host restatement."""
+    rs = np.random.RandomState(1)
+    with oracle.context(10, 2, 1) as ctx:
+        for name in ("ess_ar1", "ess_pima_chain"):
+            g = np.load(os.path.join(GOLDEN, name + ".npz"))
+            assert np.allclose(ctx.ess(g["samples"])[0], g["ess"], rtol=1e-10)
+        x = np.cumsum(rs.randn(3, 401, 4), axis=1) * 0.1 + rs.randn(3, 401, 4)   # odd S
+        ref = np.stack([tools.CalculateESS(x[i], 400, nfft="matlab").ravel() for i in range(3)])
+        assert np.allclose(ctx.ess(x), ref, rtol=1e-10)
+    d = np.load(os.path.join(GOLDEN, "data_pima.npz"))
+    with oracle.context(d["XX"].shape[0], d["XX"].shape[1], 3) as ctx:
+        ctx.set_data(d["XX"], d["t"])
+        s, acc, steps, _ = ctx.sample(40, 10, seed=2)
+        st = ctx.sample_stats(40, 10, seed=2)
+    assert np.allclose(st["mean"], s.mean(1)) and np.allclose(st["var"], s.var(1))
+    assert np.array_equal(st["accepted"], acc) and np.array_equal(st["leapfrog_steps"], steps)
+    ref = np.stack([tools.CalculateESS(s[i], 29, nfft="matlab").ravel() for i in range(3)])
+    assert np.allclose(st["ess"], ref, rtol=1e-9)
