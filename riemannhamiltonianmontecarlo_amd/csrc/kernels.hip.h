@@ -567,23 +567,28 @@ __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, d
   if (bad && lane == 0) ch.status[c] |= 1;  // RMHMC_ST_NOT_PD
 }
 
+// The per-chain vector kernels below run one wavefront per chain and stride the lanes over the dimensions
+// (d = lane, lane+64, ...), so they serve D <= 64 and the large-D path (D <= 256) alike.
+#define RM_DMAX 256
+#define RM_DCH 4   // RM_DMAX / 64 dimension chunks per lane
+
 // accept the position iterate as the new w and apply the position guard (rmhmc.py:123-130)
 __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int guards) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
-  double w = (lane < D) ? ch.wq[(size_t)c * DP + lane] : 0.0;
-  if (guards) {
-    const double nw = sqrt(wave_sum(w * w));
-    if (nw > 10.0) {
-      w /= nw * 3.0;
-      if (lane == 0) ch.status[c] |= 8;  // RMHMC_ST_GUARD_W
-    }
+  const size_t o = (size_t)c * DP;
+  double ss = 0.0;
+  for (int d = lane; d < D; d += 64) { const double w = ch.wq[o + d]; ss = fma(w, w, ss); }
+  const double nw = sqrt(wave_sum(ss));
+  const bool fire = guards && nw > 10.0;
+  for (int d = lane; d < D; d += 64) {
+    double w = ch.wq[o + d];
+    if (fire) w /= nw * 3.0;
+    ch.trj.w[o + d] = w;
+    ch.wq[o + d] = w;
   }
-  if (lane < D) {
-    ch.trj.w[(size_t)c * DP + lane] = w;
-    ch.wq[(size_t)c * DP + lane] = w;
-  }
+  if (fire && lane == 0) ch.status[c] |= 8;  // RMHMC_ST_GUARD_W
 }
 
 // new point: factor G(w), half log-determinant, explicit inverse, log joint, and u = G^-1 p
@@ -661,26 +666,34 @@ __global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, co
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
-  double u = 0.0;
+  double u[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < D; ++j) {
     const double sj = src[(size_t)c * DP + j];
-    if (lane < D) u = fma(Gi[j * DP + lane], sj, u);  // symmetric: row j read coalesced
+#pragma unroll
+    for (int k = 0; k < RM_DCH; ++k) {
+      const int d = lane + 64 * k;
+      if (d < D) u[k] = fma(Gi[j * DP + d], sj, u[k]);  // symmetric: row j read coalesced
+    }
   }
-  if (lane < D) ch.uq[(size_t)c * DP + lane] = u;
+#pragma unroll
+  for (int k = 0; k < RM_DCH; ++k)
+    if (lane + 64 * k < D) ch.uq[(size_t)c * DP + lane + 64 * k] = u[k];
 }
 
 // PM = p + tau*eps/2 * (grad - tr/2 + q/2)   (rmhmc.py:108); final != 0: p = PM (rmhmc.py:110)
 __global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, double eps, int final, int nsplit) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
-  if (ch.phase[c] != 1 || lane >= D) return;
-  const size_t o = (size_t)c * DP + lane;
+  if (ch.phase[c] != 1) return;
   const double h = ch.tau[c] * eps * 0.5;
-  double q = 0.0;
-  for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + lane];
-  const double pm = ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
-  if (final) ch.p[o] = pm;
-  else ch.PM[o] = pm;
+  for (int d = lane; d < D; d += 64) {
+    const size_t o = (size_t)c * DP + d;
+    double q = 0.0;
+    for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + d];
+    const double pm = ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
+    if (final) ch.p[o] = pm;
+    else ch.PM[o] = pm;
+  }
 }
 
 // explicit momentum half step at the new point (rmhmc.py:163) + step bookkeeping
@@ -688,18 +701,17 @@ __global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, doub
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
-  const size_t o = (size_t)c * DP + lane;
-  double pn = 0.0, wn = 0.0;
-  if (lane < D) {
-    const double h = ch.tau[c] * eps * 0.5;
+  const double h = ch.tau[c] * eps * 0.5;
+  int nonfinite = 0;
+  for (int d = lane; d < D; d += 64) {
+    const size_t o = (size_t)c * DP + d;
     double q = 0.0;
-    for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + lane];
+    for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + d];
     ch.last[o] = q;
-    pn = advance ? ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q) : ch.p[o];
-    wn = ch.trj.w[o];
+    const double pn = advance ? ch.p[o] + h * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q) : ch.p[o];
     if (advance) ch.p[o] = pn;
+    nonfinite |= !(isfinite(pn) && isfinite(ch.trj.w[o]));
   }
-  const int nonfinite = !(isfinite(pn) && isfinite(wn));
   const unsigned long long any = __ballot(nonfinite);
   if (lane == 0) {
     if (any) ch.status[c] |= 2;  // RMHMC_ST_NONFINITE
@@ -728,16 +740,16 @@ struct IterParams {
 
 __device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, int D, int DP, int lane) {
   const size_t o = (size_t)c * DP;
-  if (lane < D) {
-    dst.w[o + lane] = src.w[o + lane];
-    dst.grad[o + lane] = src.grad[o + lane];
-    dst.tr[o + lane] = src.tr[o + lane];
+  for (int d = lane; d < D; d += 64) {
+    dst.w[o + d] = src.w[o + d];
+    dst.grad[o + d] = src.grad[o + d];
+    dst.tr[o + d] = src.tr[o + d];
   }
   const size_t m = (size_t)c * DP * DP;
   for (int i = 0; i < D; ++i)
-    if (lane < D) {
-      dst.L[m + i * DP + lane] = src.L[m + i * DP + lane];
-      dst.Ginv[m + i * DP + lane] = src.Ginv[m + i * DP + lane];
+    for (int d = lane; d < D; d += 64) {
+      dst.L[m + i * DP + d] = src.L[m + i * DP + d];
+      dst.Ginv[m + i * DP + d] = src.Ginv[m + i * DP + d];
     }
   if (lane == 0) {
     dst.ljl[c] = src.ljl[c];
@@ -745,17 +757,44 @@ __device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, 
   }
 }
 
-// 0.5 * p' Ginv p for the chain's vector held one element per lane
-__device__ __forceinline__ double half_quadform(const double* __restrict__ Gi, int D, int DP, int lane, double pl) {
-  double y = 0.0;
+// 0.5 * p' Ginv p for the chain's vector ps[0..D) in LDS
+__device__ __forceinline__ double half_quadform(const double* __restrict__ Gi, int D, int DP, int lane, const double* ps) {
+  double y[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < D; ++j) {
-    const double pj = __shfl(pl, j, 64);
-    if (lane < D) y = fma(Gi[j * DP + lane], pj, y);
+    const double pj = ps[j];
+#pragma unroll
+    for (int k = 0; k < RM_DCH; ++k) {
+      const int d = lane + 64 * k;
+      if (d < D) y[k] = fma(Gi[j * DP + d], pj, y[k]);
+    }
   }
-  return 0.5 * wave_sum((lane < D) ? y * pl : 0.0);
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < RM_DCH; ++k)
+    if (lane + 64 * k < D) s = fma(y[k], ps[lane + 64 * k], s);
+  return 0.5 * wave_sum(s);
+}
+
+// D standard normals of (seed, chain, iteration) into zs[] (or the caller-supplied draws)
+__device__ __forceinline__ void draw_normals(const IterParams& ip, int c, long long it, int D, int lane, double* zs) {
+  for (int d = lane; d < D; d += 64) {
+    if (ip.z_in) {
+      zs[d] = ip.z_in[(size_t)c * D + d];
+    } else {
+      double U0, U1;
+      rng_block(ip.seed, (unsigned long long)(ip.chain_offset + c), (uint32_t)it, (uint32_t)(d >> 1), U0, U1);
+      const double R = sqrt(-2.0 * log(U0));
+      double sn, cs;
+      sincos(RM_PI2 * U1, &sn, &cs);
+      zs[d] = (d & 1) ? R * sn : R * cs;
+    }
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, IterParams ip) {
+  __shared__ double zs[RM_DMAX];
+  __shared__ double ps[RM_DMAX];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 0) return;
@@ -764,49 +803,63 @@ __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, Ite
   // trajectory starts from the cached record of the current point (wNew = w.copy(), rmhmc.py:47)
   copy_rec(ch.trj, ch.cur, c, D, DP, lane);
   // draws: z ~ randn(1,D), u_len ~ rand(), g_dir ~ randn()   (rmhmc.py:80,89,90)
-  double z = 0.0, u_len, g_dir;
+  draw_normals(ip, c, it, D, lane, zs);
+  double u_len, g_dir;
   if (ip.z_in) {
-    z = (lane < D) ? ip.z_in[(size_t)c * D + lane] : 0.0;
     u_len = ip.ulen_in[c];
     g_dir = ip.gdir_in[c];
   } else {
     const unsigned long long gid = (unsigned long long)(ip.chain_offset + c);
-    double U0, U1;
-    rng_block(ip.seed, gid, (uint32_t)it, (uint32_t)(lane >> 1), U0, U1);
-    const double R = sqrt(-2.0 * log(U0));
-    double sn, cs;
-    sincos(RM_PI2 * U1, &sn, &cs);
-    z = (lane < D) ? ((lane & 1) ? R * sn : R * cs) : 0.0;
-    double Ua;
+    double U0, U1, Ua;
     rng_block(ip.seed, gid, (uint32_t)it, 0x40000000u, u_len, Ua);
     rng_block(ip.seed, gid, (uint32_t)it, 0x40000001u, U0, U1);
     g_dir = sqrt(-2.0 * log(U0)) * cos(RM_PI2 * U1);
   }
   // momentum p = L' z (reference, rmhmc.py:60,80) or L z (corrected)
   const double* __restrict__ Lc = ch.cur.L + (size_t)c * DP * DP;
-  double p = 0.0;
+  double p[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
   if (ip.flags & 1u) {
     for (int i = 0; i < D; ++i) {
-      const double zi = __shfl(z, i, 64);
-      if (lane <= i) p = fma(Lc[i * DP + lane], zi, p);
+      const double zi = zs[i];
+#pragma unroll
+      for (int k = 0; k < RM_DCH; ++k) {
+        const int d = lane + 64 * k;
+        if (d <= i) p[k] = fma(Lc[i * DP + d], zi, p[k]);
+      }
     }
   } else {
     for (int j = 0; j < D; ++j) {
-      const double zj = __shfl(z, j, 64);
-      if (lane >= j && lane < D) p = fma(Lc[lane * DP + j], zj, p);
+      const double zj = zs[j];
+#pragma unroll
+      for (int k = 0; k < RM_DCH; ++k) {
+        const int d = lane + 64 * k;
+        if (d >= j && d < D) p[k] = fma(Lc[d * DP + j], zj, p[k]);
+      }
     }
   }
-  if (lane >= D) p = 0.0;
   int st = 0;
   if (ip.flags & 2u) {  // momentum guard, rmhmc.py:81-85
-    const double np_ = sqrt(wave_sum(p * p));
-    if (np_ > 100.0) { p /= np_ * 25.0; st = 4; }
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < RM_DCH; ++k) ss = fma(p[k], p[k], ss);
+    const double np_ = sqrt(wave_sum(ss));
+    if (np_ > 100.0) {
+#pragma unroll
+      for (int k = 0; k < RM_DCH; ++k) p[k] /= np_ * 25.0;
+      st = 4;
+    }
   }
-  const double quad = half_quadform(ch.cur.Ginv + (size_t)c * DP * DP, D, DP, lane, p);
-  if (lane < D) {
-    ch.p[(size_t)c * DP + lane] = p;
-    ch.p0[(size_t)c * DP + lane] = p;
+#pragma unroll
+  for (int k = 0; k < RM_DCH; ++k) {
+    const int d = lane + 64 * k;
+    if (d < D) {
+      ps[d] = p[k];
+      ch.p[(size_t)c * DP + d] = p[k];
+      ch.p0[(size_t)c * DP + d] = p[k];
+    }
   }
+  __syncthreads();
+  const double quad = half_quadform(ch.cur.Ginv + (size_t)c * DP * DP, D, DP, lane, ps);
   if (lane == 0) {
     const int ns = (int)ceil(u_len * (double)ip.L);  // rmhmc.py:89
     ch.steps_left[c] = ns;
@@ -819,13 +872,15 @@ __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, Ite
 }
 
 __global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterParams ip) {
+  __shared__ double ps[RM_DMAX];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   const int ph = ch.phase[c];
   if (!(ph == 2 || (ph == 1 && ch.steps_left[c] == 0))) return;
   const long long it = ch.iter[c];
-  const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
-  const double quad = half_quadform(ch.trj.Ginv + (size_t)c * DP * DP, D, DP, lane, pl);
+  for (int d = lane; d < D; d += 64) ps[d] = ch.p[(size_t)c * DP + d];
+  __syncthreads();
+  const double quad = half_quadform(ch.trj.Ginv + (size_t)c * DP * DP, D, DP, lane, ps);
   const double Hp = -ch.trj.ljl[c] + ch.trj.hld[c] + quad;  // rmhmc.py:171-172
   const double ratio = -Hp + ch.Hcur[c];                     // rmhmc.py:179
   double u_acc;
@@ -838,8 +893,9 @@ __global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterP
   const bool accept = (ratio > 0.0) || (ratio > log(u_acc));  // rmhmc.py:181
   if (accept) copy_rec(ch.cur, ch.trj, c, D, DP, lane);
   __syncthreads();
-  if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S && lane < D)
-    ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + lane] = ch.cur.w[(size_t)c * DP + lane];
+  if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S)
+    for (int d = lane; d < D; d += 64)
+      ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + d] = ch.cur.w[(size_t)c * DP + d];
   if (lane == 0) {
     ch.Hprop[c] = Hp;
     if (accept) ch.accepted[c] += 1;
@@ -861,22 +917,22 @@ __global__ __launch_bounds__(64) void k_commit_all(int D, int DP, Chains ch) {
 // sum the row-split partials of k_rowpass<RP_G> into trj.grad / trj.ljl (hmc.py:53,61,64-67)
 __device__ __forceinline__ void hmc_finish_eval(const DevData& dd, const Chains& ch, int c, int lane, int nsplit) {
   const int D = dd.D, DP = dd.DP;
-  const double wl = (lane < D) ? ch.trj.w[(size_t)c * DP + lane] : 0.0;
-  if (lane < D) {
-    double g = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) g += ch.gpart[((size_t)sp * ch.n + c) * DP + lane];
-    ch.trj.grad[(size_t)c * DP + lane] = g - wl * dd.inv_alpha;
-  }
   double part = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    const double wl = ch.trj.w[(size_t)c * DP + d];
+    double g = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) g += ch.gpart[((size_t)sp * ch.n + c) * DP + d];
+    ch.trj.grad[(size_t)c * DP + d] = g - wl * dd.inv_alpha;
+    part += dd.log_prior_const - wl * wl * 0.5 * dd.inv_alpha;
+  }
   for (int b = lane; b < nsplit; b += 64) part += ch.ljl_part[(size_t)c * nsplit + b];
-  part += (lane < D) ? (dd.log_prior_const - wl * wl * 0.5 * dd.inv_alpha) : 0.0;
   const double ljl = wave_sum(part);
   if (lane == 0) ch.trj.ljl[c] = ljl;
 }
 __device__ __forceinline__ void hmc_copy(const Rec& dst, const Rec& src, int c, int D, int DP, int lane) {
-  if (lane < D) {
-    dst.w[(size_t)c * DP + lane] = src.w[(size_t)c * DP + lane];
-    dst.grad[(size_t)c * DP + lane] = src.grad[(size_t)c * DP + lane];
+  for (int d = lane; d < D; d += 64) {
+    dst.w[(size_t)c * DP + d] = src.w[(size_t)c * DP + d];
+    dst.grad[(size_t)c * DP + d] = src.grad[(size_t)c * DP + d];
   }
   if (lane == 0) dst.ljl[c] = src.ljl[c];
 }
@@ -889,27 +945,27 @@ __global__ __launch_bounds__(64) void k_hmc_init(DevData dd, Chains ch, int nspl
 }
 // start a transition (hmc.py:41-48,72)
 __global__ __launch_bounds__(64) void k_hmc_begin(int D, int DP, Chains ch, IterParams ip) {
+  __shared__ double zs[RM_DMAX];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 0) return;
   const long long it = ch.iter[c];
   if (it >= ip.iter_limit) return;
   hmc_copy(ch.trj, ch.cur, c, D, DP, lane);
-  double z = 0.0, u_len;
+  draw_normals(ip, c, it, D, lane, zs);
+  double u_len;
   if (ip.z_in) {
-    z = (lane < D) ? ip.z_in[(size_t)c * D + lane] : 0.0;
     u_len = ip.ulen_in[c];
   } else {
-    const unsigned long long gid = (unsigned long long)(ip.chain_offset + c);
-    double U0, U1, Ua;
-    rng_block(ip.seed, gid, (uint32_t)it, (uint32_t)(lane >> 1), U0, U1);
-    const double R = sqrt(-2.0 * log(U0));
-    double sn, cs;
-    sincos(RM_PI2 * U1, &sn, &cs);
-    z = (lane < D) ? ((lane & 1) ? R * sn : R * cs) : 0.0;
-    rng_block(ip.seed, gid, (uint32_t)it, 0x40000000u, u_len, Ua);
+    double Ua;
+    rng_block(ip.seed, (unsigned long long)(ip.chain_offset + c), (uint32_t)it, 0x40000000u, u_len, Ua);
   }
-  const double kin = 0.5 * wave_sum(z * z);
-  if (lane < D) ch.p[(size_t)c * DP + lane] = z;  // Mass = I: p = z (hmc.py:41)
+  double kin = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    const double z = zs[d];
+    kin = fma(z, z, kin);
+    ch.p[(size_t)c * DP + d] = z;  // Mass = I: p = z (hmc.py:41)
+  }
+  kin = 0.5 * wave_sum(kin);
   if (lane == 0) {
     const int ns = (int)ceil(u_len * (double)ip.L);  // hmc.py:48
     ch.steps_left[c] = ns;
@@ -923,14 +979,16 @@ __global__ __launch_bounds__(64) void k_hmc_begin(int D, int DP, Chains ch, Iter
 __global__ __launch_bounds__(64) void k_hmc_pre(int D, int DP, Chains ch, double eps) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 1) return;
-  const size_t o = (size_t)c * DP + lane;
-  double p = 0.0;
-  if (lane < D) p = ch.p[o] + eps * 0.5 * ch.trj.grad[o];
-  const unsigned long long nan = __ballot(p != p);
-  if (lane < D) {
+  int isnan_ = 0;
+  for (int d = lane; d < D; d += 64) {
+    const size_t o = (size_t)c * DP + d;
+    const double p = ch.p[o] + eps * 0.5 * ch.trj.grad[o];
     ch.p[o] = p;
-    if (!nan) ch.trj.w[o] += eps * p;
+    isnan_ |= (p != p);
   }
+  const unsigned long long nan = __ballot(isnan_);
+  if (!nan)
+    for (int d = lane; d < D; d += 64) ch.trj.w[(size_t)c * DP + d] += eps * ch.p[(size_t)c * DP + d];
   if (nan && lane == 0) { ch.status[c] |= 2; ch.steps_left[c] = 1; }
 }
 // gradient / log joint at the new position, second momentum half step (hmc.py:60-62)
@@ -939,8 +997,8 @@ __global__ __launch_bounds__(64) void k_hmc_post(DevData dd, Chains ch, double e
   if (ch.phase[c] != 1) return;
   hmc_finish_eval(dd, ch, c, lane, nsplit);
   __syncthreads();
-  const size_t o = (size_t)c * dd.DP + lane;
-  if (lane < dd.D && !(ch.status[c] & 2)) ch.p[o] += eps * 0.5 * ch.trj.grad[o];
+  if (!(ch.status[c] & 2))
+    for (int d = lane; d < dd.D; d += 64) ch.p[(size_t)c * dd.DP + d] += eps * 0.5 * ch.trj.grad[(size_t)c * dd.DP + d];
   if (lane == 0) { ch.steps_left[c] -= 1; ch.steps_done[c] += 1; }
 }
 // finish a transition (hmc.py:64-84)
@@ -949,8 +1007,9 @@ __global__ __launch_bounds__(64) void k_hmc_end(int D, int DP, Chains ch, IterPa
   const int ph = ch.phase[c];
   if (!(ph == 2 || (ph == 1 && ch.steps_left[c] == 0))) return;
   const long long it = ch.iter[c];
-  const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
-  const double Hp = -ch.trj.ljl[c] + 0.5 * wave_sum(pl * pl);  // hmc.py:69
+  double kin = 0.0;
+  for (int d = lane; d < D; d += 64) { const double pl = ch.p[(size_t)c * DP + d]; kin = fma(pl, pl, kin); }
+  const double Hp = -ch.trj.ljl[c] + 0.5 * wave_sum(kin);  // hmc.py:69
   const double ratio = -Hp + ch.Hcur[c];
   double u_acc;
   if (ip.z_in) {
@@ -962,8 +1021,9 @@ __global__ __launch_bounds__(64) void k_hmc_end(int D, int DP, Chains ch, IterPa
   const bool accept = (ratio > 0.0) || (ratio > log(u_acc));  // hmc.py:77
   if (accept) hmc_copy(ch.cur, ch.trj, c, D, DP, lane);
   __syncthreads();
-  if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S && lane < D)
-    ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + lane] = ch.cur.w[(size_t)c * DP + lane];
+  if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S)
+    for (int d = lane; d < D; d += 64)
+      ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + d] = ch.cur.w[(size_t)c * DP + d];
   if (lane == 0) {
     ch.Hprop[c] = Hp;
     if (accept) ch.accepted[c] += 1;
