@@ -8,6 +8,7 @@
 #include "../../include/rmhmc.h"
 #include "kernels.hip.h"
 #include "fused_small.hip.h"
+#include "large_d.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -58,6 +59,10 @@ struct rmhmc_ctx {
   std::vector<void*> allocs;
   bool have_data = false, chains_ready = false;
   int sampler = 0;           // 0: RMHMC (rmhmc.py), 1: plain HMC (hmc.py) -- selects the global step
+  bool big = false;          // large-D path: 64 < D <= 256 (large_d.hip.h)
+  int nbk = 1, npairs = 1;   // 64-column blocks and block pairs of the large-D path
+  double *d_Wd = nullptr, *d_hpart = nullptr, *d_Gcopy = nullptr;
+  bool want_G = false;
   bool fused = false;        // small-problem path: D <= 8 and X fits in LDS (fused_small.hip.h)
   size_t fused_lds = 0;
   // sampler parameters of the stateful API
@@ -161,6 +166,12 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
 template <int MODE>
 void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out2 = nullptr) {
   launch(ctx, g, HEAVY, "rowpass", [&](hipStream_t st) {
+    if (ctx->big) {
+      dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
+      hipLaunchKernelGGL((k_rowpass_big<MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, g.ch.phase, w, out0, out2,
+                         g.ch.gpart, g.ch.ljl_part);
+      return;
+    }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
                                       out2, g.ch.gpart, g.ch.ljl_part));
@@ -169,6 +180,11 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
 
 void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
   launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
+    if (ctx->big) {
+      dim3 grid((unsigned)((g.n + 3) / 4), ctx->npairs);
+      hipLaunchKernelGGL(k_assemble_pair, grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, g.ch.Gq);
+      return;
+    }
     dim3 grid((unsigned)((g.n + 3) / 4));
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, g.ch.Gq));
   });
@@ -177,12 +193,32 @@ void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
 // q partials of u' dG/dw_d u for every chain (u = ch.uq, w as given); summed by k_mom_update / k_mom_final
 void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w) {
   launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
+    if (ctx->big) {
+      dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
+      hipLaunchKernelGGL(k_mompass_big, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, w, g.ch.uq, g.ch.qpart);
+      return;
+    }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart));
   });
 }
 
 void launch_leverage(rmhmc_ctx* ctx, Group& g) {
+  if (ctx->big) {  // per block pair leverage contributions, then the trace GEMM over 16 chains per workgroup
+    double* hpart = ctx->d_hpart + (size_t)g.off * ctx->Mp;  // [pair][n][Mp] of this group (single group: off = 0)
+    launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
+      dim3 grid((unsigned)((g.n + 3) / 4), ctx->npairs);
+      hipLaunchKernelGGL(k_leverage_pair, grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.Ginv, hpart);
+    });
+    launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
+      dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
+      hipLaunchKernelGGL(k_trace_big, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, ctx->npairs, g.ch.rv2, hpart, g.ch.gpart);
+    });
+    launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
+      hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
+    });
+    return;
+  }
   launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
     dim3 grid((unsigned)((g.n + 3) / 4));
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_leverage<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.Ginv, g.ch.rv2,
@@ -193,6 +229,10 @@ void launch_leverage(rmhmc_ctx* ctx, Group& g) {
 // one wavefront (64-thread block) per chain
 #define SMALL(ctx, g, name, kern, ...)                                                                     \
   launch(ctx, g, LIGHT, name, [&](hipStream_t st_) { hipLaunchKernelGGL(kern, dim3((unsigned)(g).n), dim3(64), 0, st_, __VA_ARGS__); })
+
+// one 256-thread workgroup per chain (blocked dense algebra of the large-D path)
+#define BIG(ctx, g, name, kern, ...)                                                                       \
+  launch(ctx, g, LIGHT, name, [&](hipStream_t st_) { hipLaunchKernelGGL(kern, dim3((unsigned)(g).n), dim3(256), 0, st_, __VA_ARGS__); })
 
 // A phase is one launch per group; phases are issued group-alternating so that, with two groups, the main
 // stream sees heavy(A), heavy(B), heavy(A), ... and the light kernels of a group overlap the other's heavy one.
@@ -207,8 +247,20 @@ void run_phases(rmhmc_ctx* ctx, const std::vector<Phase>& phases) {
 // -> factor / inverse / u = G^-1 p -> quadratic term -> leverage pass (trace term) -> momentum update.
 void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance) {
   ph.push_back([ctx](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv2); });
+  if (ctx->big) ph.push_back([ctx](Group& g) { SMALL(ctx, g, "small", k_finish_big, ctx->dd, g.ch, g.nsplit); });
   ph.push_back([ctx](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
-  ph.push_back([ctx](Group& g) { SMALL(ctx, g, "factor", k_factor_full, ctx->dd, g.ch, g.nsplit); });
+  if (ctx->big) {
+    ph.push_back([ctx](Group& g) {
+      if (ctx->want_G)
+        (void)hipMemcpyAsync(ctx->d_Gcopy + (size_t)g.off * ctx->DP * ctx->DP, g.ch.Gq, sizeof(double) * (size_t)g.n * ctx->DP * ctx->DP,
+                             hipMemcpyDeviceToDevice, ctx->stream);
+      BIG(ctx, g, "factor", k_chol_big<1>, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096, ctx->eps);
+    });
+    ph.push_back([ctx](Group& g) { BIG(ctx, g, "factor", k_inverse_big, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096); });
+    ph.push_back([ctx](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, ctx->D, ctx->DP, g.ch, g.ch.p); });
+  } else {
+    ph.push_back([ctx](Group& g) { SMALL(ctx, g, "factor", k_factor_full, ctx->dd, g.ch, g.nsplit); });
+  }
   ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
   ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
   ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
@@ -226,11 +278,19 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   }
   // implicit position step: K fixed-point iterations (rmhmc.py:113-123); the first one re-uses the
   // stored factor of G(w)
-  ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_pos_first, D, DP, g.ch, eps); });
+  if (ctx->big) {
+    ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, g.ch.p); });
+    ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_pos_first_big, D, DP, g.ch, eps); });
+  } else {
+    ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_pos_first, D, DP, g.ch, eps); });
+  }
   for (int it = 1; it < K; ++it) {
     ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0); });
     ph.push_back([=](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
-    ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_factor_solve, D, DP, g.ch, eps); });
+    if (ctx->big)
+      ph.push_back([=](Group& g) { BIG(ctx, g, "factor", k_chol_big<0>, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096, eps); });
+    else
+      ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_factor_solve, D, DP, g.ch, eps); });
   }
   const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
   ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_pos_final, D, DP, g.ch, guards); });
@@ -410,7 +470,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   rmhmc_ctx* ctx = nullptr;  // for the macros: errors go to the global message
   if (!out || M <= 0 || D <= 0 || n_chains <= 0) return fail(nullptr, RMHMC_ERR_INVALID, "rmhmc_create: bad shape");
   if (dtype != RMHMC_F64) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: only float64 is built (the reference is float64)");
-  if (D > 64) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: D > 64 needs the tiled-Cholesky path, which is not built yet");
+  if (D > 256) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: D > 256 is not supported (64 < D <= 256 uses the blocked large-D path)");
   if (flags & RMHMC_FLAG_ORACLE_LITERAL) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: the literal variant exists only in the CPU oracle");
   if (M > (int64_t)1 << 30 || n_chains > (int64_t)1 << 30) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: M or n_chains too large");
   int ndev = 0;
@@ -426,6 +486,13 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   ctx->device = device_id;
   ctx->M = M; ctx->D = D; ctx->n = n_chains; ctx->flags = flags;
   ctx->NB = (D + 15) / 16; ctx->DP = 16 * ctx->NB;
+  if (D > 64) {  // large-D path: 64-column blocks, NB = 4 tiles inside a block
+    ctx->big = true;
+    ctx->nbk = (D + 63) / 64;
+    ctx->npairs = ctx->nbk * (ctx->nbk + 1) / 2;
+    ctx->DP = 64 * ctx->nbk;
+    ctx->NB = 4;
+  }
   ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
   int rc = RMHMC_OK;
   auto body = [&]() -> int {
@@ -453,7 +520,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     // the default is a single group on one stream.
     int ngroups = 1;
     if (const char* e = getenv("RMHMC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 4) ngroups = v; }
-    if (n_chains < 64 * ngroups) ngroups = 1;
+    if (n_chains < 64 * ngroups || ctx->big) ngroups = 1;
     int hiprio = ngroups > 1 ? 1 : 0;
     if (const char* e = getenv("RMHMC_PRIO")) hiprio = atoi(e) ? 1 : 0;
     ctx->groups.resize(ngroups);
@@ -484,6 +551,10 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       HIPCK(hipEventCreateWithFlags(&ctx->fj_event, hipEventDisableTiming));
     }
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
+    if (ctx->big) {
+      RC(dalloc(ctx, &ctx->d_Wd, n * (size_t)ctx->nbk * 4096));
+      RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * n * Mp));
+    }
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
     {  // small-problem path eligibility (RMHMC_FUSED=0 disables it)
       const size_t lds = ((size_t)(FS_D + 1 + FS_WAVES) * ctx->Mp + (size_t)FS_WAVES * FS_PT) * sizeof(double);
@@ -572,11 +643,15 @@ int rmhmc_metric(rmhmc_ctx* ctx, const double* w, double* G_out, double* half_lo
   NEED_DATA(ctx);
   if (!w) return fail(ctx, RMHMC_ERR_INVALID, "metric: null pointer");
   ctx->chains_ready = false;
-  RC(eval_at(ctx, w, nullptr));
+  if (ctx->big && G_out && !ctx->d_Gcopy) RC(dalloc(ctx, &ctx->d_Gcopy, (size_t)ctx->n * ctx->DP * ctx->DP));
+  ctx->want_G = ctx->big && G_out;
+  int rc_eval = eval_at(ctx, w, nullptr);
+  ctx->want_G = false;
+  RC(rc_eval);
   join_streams(ctx);
   if (G_out)
     for (int64_t c = 0; c < ctx->n; ++c)  // strip the padding: [DP][DP] -> [D][D]
-      HIPCK(hipMemcpy2DAsync(G_out + c * ctx->D * ctx->D, ctx->D * 8, ctx->ch.Gq + c * ctx->DP * ctx->DP, ctx->DP * 8, ctx->D * 8, ctx->D,
+      HIPCK(hipMemcpy2DAsync(G_out + c * ctx->D * ctx->D, ctx->D * 8, (ctx->big ? ctx->d_Gcopy : ctx->ch.Gq) + c * ctx->DP * ctx->DP, ctx->DP * 8, ctx->D * 8, ctx->D,
                              hipMemcpyDeviceToHost, ctx->stream));
   if (half_logdet_out) RC(download(ctx, half_logdet_out, ctx->ch.trj.hld, ctx->n));
   if (grad_out) RC(download_vec(ctx, grad_out, ctx->ch.trj.grad));

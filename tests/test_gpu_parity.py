@@ -241,7 +241,7 @@ def test_shim_contract_and_posterior(hip):
 
 def test_errors(hip):
     with pytest.raises(_capi.RmhmcError) as e:
-        hip.context(100, 65, 1)
+        hip.context(100, 257, 1)
     assert e.value.code == -4
     with hip.context(10, 2, 1) as ctx:
         with pytest.raises(_capi.RmhmcError):
@@ -376,3 +376,53 @@ def test_device_ess_matches_reference_and_host(hip, oracle):
     a, b = _both(hip, oracle, 300, 12, 7, fn)
     assert np.array_equal(a["accepted"], b["accepted"]) and np.array_equal(a["leapfrog_steps"], b["leapfrog_steps"])
     assert rel_err(a["mean"], b["mean"]) < 1e-7 and rel_err(a["var"], b["var"]) < 1e-6 and rel_err(a["ess"], b["ess"]) < 1e-5
+
+
+# ---- large-D path (64 < D <= 256, BASELINE config 5 shape: blocked Cholesky, 64-column blocks) -------------------------
+BIG_SHAPES = [(300, 100, 3), (200, 130, 2), (260, 256, 2), (150, 65, 5), (400, 192, 18)]
+
+
+@pytest.mark.parametrize("M,D,n", BIG_SHAPES)
+def test_large_d_callbacks_match_oracle(hip, oracle, M, D, n):
+    rs = np.random.RandomState(M + D)
+    w = 0.3 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
+
+    def fn(ctx):
+        return (ctx.log_posterior(w),) + ctx.metric(w) + ctx.metric_terms(w, p)
+
+    (lg, Gg, hg, gg, tg, qg), (lo, Go, ho, go, to, qo) = _both(hip, oracle, M, D, n, fn)
+    assert rel_err(lg, lo) < 1e-12
+    assert rel_err(Gg, Go) < 1e-12 and np.array_equal(Gg, np.swapaxes(Gg, 1, 2))
+    assert rel_err(gg, go) < 1e-11
+    assert rel_err(hg, ho) < 1e-11
+    assert rel_err(tg, to) < 1e-8
+    assert rel_err(qg, qo) < 1e-8
+
+
+@pytest.mark.parametrize("M,D,n", BIG_SHAPES)
+def test_large_d_leapfrog_and_transition_match_oracle(hip, oracle, M, D, n):
+    rs = np.random.RandomState(3 * M + D)
+    w = 0.2 * rs.randn(n, D) / np.sqrt(D); p = 2.0 * rs.randn(n, D)
+    ns = rs.randint(0, 3, size=n).astype(np.int32); ns[0] = 1
+    dr = np.where(rs.rand(n) < 0.5, 1, -1).astype(np.int32)
+    z = rs.randn(n, D); ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
+
+    def fn(ctx):
+        return ctx.leapfrog(w, p, 0.3, dr, ns, 4), ctx.transition(w, z, ul, gd, ua, L=3, eps=0.3, K=4)
+
+    (lg, tg), (lo, to) = _both(hip, oracle, M, D, n, fn)
+    assert rel_err(lg[0], lo[0]) < TOL_TRAJ and rel_err(lg[1], lo[1]) < TOL_TRAJ and rel_err(lg[2], lo[2]) < TOL_TRAJ
+    assert np.array_equal(tg["nsteps"], to["nsteps"]) and np.array_equal(tg["accepted"], to["accepted"])
+    assert rel_err(tg["w_prop"], to["w_prop"]) < TOL_TRAJ and rel_err(tg["p_prop"], to["p_prop"]) < TOL_TRAJ
+    assert rel_err(tg["H_prop"], to["H_prop"]) < 1e-8 and rel_err(tg["H_cur"], to["H_cur"]) < 1e-9
+
+
+def test_large_d_sampler_and_hmc_match_oracle(hip, oracle):
+    M, D, n = 250, 150, 4
+
+    def fn(ctx):
+        return ctx.sample(7, 2, L=3, eps=0.3, seed=8, chain_offset=1), ctx.hmc_sample(6, 2, L=8, eps=0.05, seed=9)
+
+    (sg, hg), (so, ho) = _both(hip, oracle, M, D, n, fn)
+    assert np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2]) and rel_err(sg[0], so[0]) < 1e-7
+    assert np.array_equal(hg[1], ho[1]) and np.array_equal(hg[2], ho[2]) and rel_err(hg[0], ho[0]) < 1e-8
