@@ -13,6 +13,7 @@ Workloads (BASELINE.json configs):
       on; with --gpus 8 it is config 4: 65536 chains sharded 8192 per GPU, weak scaling)
   c2  1024 chains, D=8, M=1000
   c1  bundled australian data (M=690, D=15), 1 chain
+  c5  4096 chains, D=256, M=50000 (large-D path)
 
 Extra objects in the JSON line: "roofline" (dominant kernel = metric assembly, timed with HIP events
 on the library's stream inside the timed region) and "cpu_baseline" (the CPU oracle timed on the
@@ -36,6 +37,7 @@ WORKLOADS = {
     "c3": dict(chains=8192, D=64, M=10000, desc="BASELINE config 3/4: 8192 chains per GPU, D=64, M=10000 synthetic logistic regression"),
     "c2": dict(chains=1024, D=8, M=1000, desc="BASELINE config 2: 1024 chains, D=8, M=1000 synthetic logistic regression"),
     "c1": dict(chains=1, D=15, M=690, desc="BASELINE config 1: bundled australian data, 1 chain"),
+    "c5": dict(chains=4096, D=256, M=50000, desc="BASELINE config 5: 4096 chains, D=256, M=50000 (blocked Cholesky, 64-column blocks)"),
 }
 
 
@@ -205,15 +207,27 @@ def main():
         elif a_n > 0:
             a_avg = a_s / a_n
             achieved = pass_bytes / a_avg
-            roof = {"bound": "hbm", "kernel": "k_assemble (X' diag(v) X on fp64 MFMA)", "achieved": achieved / 1e9,
-                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
-                    "avg_launch_ms": a_avg * 1e3, "launches": a_n,
-                    "mfma_tflops": (n * M * (D / 16.0) * (D / 16.0 + 1) / 2 * 2048.0 / 4.0) / a_avg / 1e12,
-                    "mfma_frac": (n * M * (D / 16.0) * (D / 16.0 + 1) / 2 * 2048.0 / 4.0) / a_avg / FP64_MFMA_PEAK,
-                    "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
-                    "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
-                    "note": "achieved = algorithmic bytes (8*M*D per chain per pass) / measured launch time; X is shared by all "
-                            "chains and cache resident, so DRAM traffic is far below the algorithmic bytes (see DESIGN.md)"}
+            if D > 64:  # large-D path: one launch = all block pairs; compute bound (AI above the ridge)
+                nbk = (D + 63) // 64
+                tiles = nbk * 10 + (nbk * (nbk + 1) // 2 - nbk) * 16
+                fl = n * (M / 4.0) * tiles * 2048.0
+                roof = {"bound": "mfma", "kernel": "k_assemble_pair (X' diag(v) X, one wave per (chain, 64-column block pair), fp64 MFMA)",
+                        "achieved": fl / a_avg / 1e12, "peak": FP64_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / a_avg / FP64_MFMA_PEAK,
+                        "traffic": None, "avg_launch_ms": a_avg * 1e3, "launches": a_n,
+                        "alg_hbm_gbs": achieved / 1e9, "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
+                        "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
+                        "note": "achieved = MFMA flops issued by one assembly launch (all block pairs) / measured launch time"}
+            else:
+                nb16 = (D + 15) // 16
+                fl = n * (M / 4.0) * (nb16 * (nb16 + 1) // 2) * 2048.0
+                roof = {"bound": "hbm", "kernel": "k_assemble (X' diag(v) X on fp64 MFMA)", "achieved": achieved / 1e9,
+                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                        "avg_launch_ms": a_avg * 1e3, "launches": a_n,
+                        "mfma_tflops": fl / a_avg / 1e12, "mfma_frac": fl / a_avg / FP64_MFMA_PEAK,
+                        "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
+                        "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
+                        "note": "achieved = algorithmic bytes (8*M*D per chain per pass) / measured launch time; X is shared by all "
+                                "chains and cache resident, so DRAM traffic is far below the algorithmic bytes (see DESIGN.md)"}
             pmc = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
             if os.path.exists(pmc):
                 roof["traffic"] = json.load(open(pmc)).get("assemble_bytes_per_launch")

@@ -257,6 +257,9 @@ __global__ __launch_bounds__(64) void k_finish_big(DevData dd, Chains ch, int ns
 // ---------------------------------------------------------------------------------------------------------------
 // metric blocks and leverage contributions, one wavefront per (chain, block pair)
 // ---------------------------------------------------------------------------------------------------------------
+// DIAG: blockIdx.y = diagonal block (10 tiles); otherwise blockIdx.y enumerates the pairs bA < bB (16 tiles).  Two
+// instantiations instead of a run-time branch: with both tile sets in one kernel the register allocation doubles.
+template <bool DIAG>
 __global__ __launch_bounds__(256) void k_assemble_pair(DevData dd, int n_chains, const int* __restrict__ phase,
                                                        const double* __restrict__ vrow, double* __restrict__ Gq) {
   constexpr int NB = 4;
@@ -266,8 +269,14 @@ __global__ __launch_bounds__(256) void k_assemble_pair(DevData dd, int n_chains,
   if (c >= n_chains) return;
   if (phase[c] != 1) return;
   int bA, bB;
-  pair_from_index(blockIdx.y, bA, bB);
-  const bool diag = (bA == bB);
+  if (DIAG) {
+    bA = bB = blockIdx.y;
+  } else {  // pair index p -> (bA < bB): p = bB(bB-1)/2 + bA
+    bB = 1;
+    while (bB * (bB + 1) / 2 <= (int)blockIdx.y) ++bB;
+    bA = blockIdx.y - bB * (bB - 1) / 2;
+  }
+  constexpr bool diag = DIAG;
   const int rr = lane >> 4, ci = lane & 15;
   const double* __restrict__ xpA = dd.Xr + (size_t)rr * DP + 64 * bA + NB * ci;
   const double* __restrict__ xpB = dd.Xr + (size_t)rr * DP + 64 * bB + NB * ci;
@@ -277,10 +286,12 @@ __global__ __launch_bounds__(256) void k_assemble_pair(DevData dd, int n_chains,
   for (int I = 0; I < NB; ++I)
 #pragma unroll
     for (int J = 0; J < NB; ++J) acc[I][J] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int n1 = 0; n1 < dd.Mp; n1 += 16) {
-    double xa[4][NB], xb[4][NB], vv[4];
+  // software pipeline over groups of 2 MFMA k-chunks (8 data rows): the operands of the next group are requested
+  // before the 2*16 MFMAs of the current one (Mp is a multiple of 64, so groups come in pairs)
+  double xaA[2][NB], xbA[2][NB], vA[2], xaB[2][NB], xbB[2][NB], vB[2];
+  auto load_group = [&](double (&xa)[2][NB], double (&xb)[2][NB], double (&vv)[2], int n1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
         xa[q][I] = xpA[(size_t)(n1 + 4 * q) * DP + I];
@@ -288,22 +299,32 @@ __global__ __launch_bounds__(256) void k_assemble_pair(DevData dd, int n_chains,
       }
       vv[q] = vp[n1 + 4 * q];
     }
+  };
+  auto compute_group = [&](const double (&xa)[2][NB], const double (&xb)[2][NB], const double (&vv)[2]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
+      double xs[NB];
 #pragma unroll
-      for (int I = 0; I < NB; ++I) xa[q][I] *= vv[q];
+      for (int I = 0; I < NB; ++I) xs[I] = xa[q][I] * vv[q];
       if (diag) {
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
-          for (int J = I; J < NB; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q][I], xb[q][J], acc[I][J], 0, 0, 0);
+          for (int J = I; J < NB; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[I], xb[q][J], acc[I][J], 0, 0, 0);
       } else {
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
-          for (int J = 0; J < NB; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q][I], xb[q][J], acc[I][J], 0, 0, 0);
+          for (int J = 0; J < NB; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[I], xb[q][J], acc[I][J], 0, 0, 0);
       }
     }
+  };
+  load_group(xaA, xbA, vA, 0);
+  for (int n1 = 0; n1 < dd.Mp; n1 += 16) {
+    load_group(xaB, xbB, vB, n1 + 8);
+    compute_group(xaA, xbA, vA);
+    if (n1 + 16 < dd.Mp) load_group(xaA, xbA, vA, n1 + 16);
+    compute_group(xaB, xbB, vB);
   }
   double* __restrict__ G = Gq + (size_t)c * DP * DP;
 #pragma unroll

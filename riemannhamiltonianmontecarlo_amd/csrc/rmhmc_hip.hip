@@ -181,8 +181,10 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
 void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
   launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
     if (ctx->big) {
-      dim3 grid((unsigned)((g.n + 3) / 4), ctx->npairs);
-      hipLaunchKernelGGL(k_assemble_pair, grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, g.ch.Gq);
+      hipLaunchKernelGGL(k_assemble_pair<false>, dim3((unsigned)((g.n + 3) / 4), ctx->npairs - ctx->nbk), dim3(256), 0, st, ctx->dd, g.n,
+                         g.ch.phase, v, g.ch.Gq);
+      hipLaunchKernelGGL(k_assemble_pair<true>, dim3((unsigned)((g.n + 3) / 4), ctx->nbk), dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v,
+                         g.ch.Gq);
       return;
     }
     dim3 grid((unsigned)((g.n + 3) / 4));
