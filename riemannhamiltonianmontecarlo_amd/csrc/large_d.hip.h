@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256) void k_assemble_pair(DevData dd, int n_chains,
 }
 
 // hpart[pair][chain][n] = x_A' Ghat_AB x_B  (Ghat_AB = 2 G^-1_AB for bA < bB; the folded upper triangle on the diagonal)
-__global__ __launch_bounds__(256) void k_leverage_pair(DevData dd, int n_chains, const int* __restrict__ phase,
+// DIAG: blockIdx.y = diagonal block, hpart slot blockIdx.y; otherwise blockIdx.y enumerates bA < bB, slot nbk + blockIdx.y.
+template <bool DIAG>
+__global__ __launch_bounds__(256) void k_leverage_pair(DevData dd, int n_chains, int nbk, const int* __restrict__ phase,
                                                        const double* __restrict__ Ginv, double* __restrict__ hpart) {
   constexpr int NB = 4;
   const int DP = dd.DP;
@@ -356,8 +358,14 @@ __global__ __launch_bounds__(256) void k_leverage_pair(DevData dd, int n_chains,
   if (c >= n_chains) return;
   if (phase[c] != 1) return;
   int bA, bB;
-  pair_from_index(blockIdx.y, bA, bB);
-  const bool diag = (bA == bB);
+  if (DIAG) {
+    bA = bB = blockIdx.y;
+  } else {
+    bB = 1;
+    while (bB * (bB + 1) / 2 <= (int)blockIdx.y) ++bB;
+    bA = blockIdx.y - bB * (bB - 1) / 2;
+  }
+  const int slot = DIAG ? (int)blockIdx.y : nbk + (int)blockIdx.y;
   const int rr = lane >> 4, ci = lane & 15;
   const double* __restrict__ Gi = Ginv + (size_t)c * DP * DP;
   double Gv[NB][4][NB];
@@ -368,37 +376,53 @@ __global__ __launch_bounds__(256) void k_leverage_pair(DevData dd, int n_chains,
 #pragma unroll
       for (int J = 0; J < NB; ++J) {
         const int row = 64 * bA + NB * (4 * s + rr) + I, col = 64 * bB + NB * ci + J;
-        const double g = Gi[(size_t)row * DP + col];
-        Gv[I][s][J] = diag ? ((J >= I) ? g * (I == J ? 1.0 : 2.0) : 0.0) : 2.0 * g;
+        if (DIAG) Gv[I][s][J] = (J >= I) ? Gi[(size_t)row * DP + col] * (I == J ? 1.0 : 2.0) : 0.0;
+        else Gv[I][s][J] = 2.0 * Gi[(size_t)row * DP + col];
       }
   const double* __restrict__ xpA = dd.Xr + (size_t)ci * DP + 64 * bA + NB * rr;
   const double* __restrict__ xpB = dd.Xr + (size_t)ci * DP + 64 * bB + NB * rr;
-  double* __restrict__ hp_out = hpart + ((size_t)blockIdx.y * n_chains + c) * dd.Mp;
-  for (int n0 = 0; n0 < dd.Mp; n0 += 16) {
-    double XA[4][NB], XB[4][NB];
+  double* __restrict__ hp_out = hpart + ((size_t)slot * n_chains + c) * dd.Mp;
+  // software pipeline: the operand rows of the next 16-row block are requested before the MFMAs of the current one
+  double XA0[4][NB], XA1[4][NB];
+  auto load_A = [&](double (&X)[4][NB], int n0) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) {
-        XA[s][I] = xpA[(size_t)n0 * DP + NB * 4 * s + I];
-        XB[s][I] = xpB[(size_t)n0 * DP + NB * 4 * s + I];
-      }
+      for (int I = 0; I < NB; ++I) X[s][I] = xpA[(size_t)n0 * DP + NB * 4 * s + I];
+  };
+  auto compute_block = [&](const double (&XA)[4][NB], int n0) {
+    double XB[4][NB];
+    if (!DIAG) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) XB[s][I] = xpB[(size_t)n0 * DP + NB * 4 * s + I];
+    }
     d4 Y[NB];
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
       Y[J] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int I = 0; I < NB; ++I)
+      for (int I = 0; I < NB; ++I) {
+        if (DIAG && I > J) continue;
 #pragma unroll
         for (int s = 0; s < 4; ++s) Y[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gv[I][s][J], XA[s][I], Y[J], 0, 0, 0);
+      }
     }
     double hp = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int J = 0; J < NB; ++J) hp = fma(Y[J][r], XB[r][J], hp);
+      for (int J = 0; J < NB; ++J) hp = fma(Y[J][r], DIAG ? XA[r][J] : XB[r][J], hp);
     const double h = col4_sum(hp);
     if (rr == 0) hp_out[n0 + ci] = h;
+  };
+  load_A(XA0, 0);
+  for (int n0 = 0; n0 < dd.Mp; n0 += 32) {
+    load_A(XA1, n0 + 16);
+    compute_block(XA0, n0);
+    if (n0 + 32 < dd.Mp) load_A(XA0, n0 + 32);
+    compute_block(XA1, n0 + 16);
   }
 }
 

@@ -209,8 +209,10 @@ void launch_leverage(rmhmc_ctx* ctx, Group& g) {
   if (ctx->big) {  // per block pair leverage contributions, then the trace GEMM over 16 chains per workgroup
     double* hpart = ctx->d_hpart + (size_t)g.off * ctx->Mp;  // [pair][n][Mp] of this group (single group: off = 0)
     launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
-      dim3 grid((unsigned)((g.n + 3) / 4), ctx->npairs);
-      hipLaunchKernelGGL(k_leverage_pair, grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.Ginv, hpart);
+      hipLaunchKernelGGL(k_leverage_pair<false>, dim3((unsigned)((g.n + 3) / 4), ctx->npairs - ctx->nbk), dim3(256), 0, st, ctx->dd, g.n,
+                         ctx->nbk, g.ch.phase, g.ch.trj.Ginv, hpart);
+      hipLaunchKernelGGL(k_leverage_pair<true>, dim3((unsigned)((g.n + 3) / 4), ctx->nbk), dim3(256), 0, st, ctx->dd, g.n, ctx->nbk,
+                         g.ch.phase, g.ch.trj.Ginv, hpart);
     });
     launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
