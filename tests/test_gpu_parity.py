@@ -426,3 +426,27 @@ def test_large_d_sampler_and_hmc_match_oracle(hip, oracle):
     (sg, hg), (so, ho) = _both(hip, oracle, M, D, n, fn)
     assert np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2]) and rel_err(sg[0], so[0]) < 1e-7
     assert np.array_equal(hg[1], ho[1]) and np.array_equal(hg[2], ho[2]) and rel_err(hg[0], ho[0]) < 1e-8
+
+
+def test_config5_shape_properties(hip, oracle):
+    """BASELINE config 5 shape (D = 256, tens of thousands of rows; fewer chains to bound the oracle's time): chains of
+    a residue class replay the same randomness and must agree bit for bit; one chain per class is checked against
+    the oracle."""
+    M, D, n, R = 20000, 256, 256, 4
+    XX, t = synthetic_logreg(M, D, 0)
+    rs = np.random.RandomState(11)
+    w4 = 0.02 * rs.randn(R, D); z4 = rs.randn(R, D); ul4 = rs.rand(R); gd4 = rs.randn(R); ua4 = rs.rand(R)
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (n // R,) + (1,) * (a.ndim - 1)))
+    with hip.context(M, D, n, flags=0) as ctx:
+        ctx.set_data(XX, t)
+        r = ctx.transition(rep(w4), rep(z4), rep(ul4), rep(gd4), rep(ua4), L=1, eps=0.5, K=4)
+    for k in ("w_prop", "p_prop", "H_prop", "w"):
+        a = r[k].reshape((n // R, R) + r[k].shape[1:])
+        assert np.array_equal(a, np.broadcast_to(a[0], a.shape)), k
+    with oracle.context(M, D, R, flags=0) as ctx:
+        ctx.set_data(XX, t)
+        o = ctx.transition(w4, z4, ul4, gd4, ua4, L=1, eps=0.5, K=4)
+    assert np.array_equal(r["nsteps"][:R], o["nsteps"]) and np.array_equal(r["accepted"][:R], o["accepted"])
+    assert rel_err(r["w_prop"][:R], o["w_prop"]) < TOL_TRAJ
+    assert rel_err(r["p_prop"][:R], o["p_prop"]) < TOL_TRAJ
+    assert rel_err(r["hld_prop"][:R], o["hld_prop"]) < TOL_TRAJ
