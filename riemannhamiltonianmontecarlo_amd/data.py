@@ -12,14 +12,16 @@ BASELINE configs 2-5 (no intercept, unit-variance columns).
 import numpy as np
 
 
-def load_csv_dataset(path):
+def load_csv_dataset(path, polynomial_order=1):
+    """polynomial_order=3 builds the cubic basis [1, X, X^2, X^3] the authors use for Ripley (D = 7,
+    authors_code/Bayes_Log_Reg/MCMC/BLR_RMHMC.m:151-173); 1 is main.py's [1, X]."""
     raw = np.loadtxt(path, delimiter=",")
     t = raw[:, -1:].astype(np.float64).copy()
     if set(np.unique(t)) == {1.0, 2.0}:
         t = t - 1.0
     X = raw[:, :-1]
     X = (X - X.mean(axis=0)) / X.std(axis=0)
-    XX = np.hstack([np.ones((X.shape[0], 1)), X])
+    XX = np.hstack([np.ones((X.shape[0], 1))] + [X ** i for i in range(1, polynomial_order + 1)])
     return np.ascontiguousarray(XX, dtype=np.float64), np.ascontiguousarray(t)
 
 

@@ -232,6 +232,8 @@ def main():
     for ds in ("pima", "australian", "german", "heart"):
         XX, t = load_csv_dataset(os.path.join(REF, "data", ds + ".csv"))
         save("data_" + ds, XX=XX, t=t)
+    XX, t = load_csv_dataset(os.path.join(REF, "data", "ripley.csv"), polynomial_order=3)  # cubic basis, D = 7
+    save("data_ripley", XX=XX, t=t)
     # --- transition tapes on the bundled data ------------------------------------------------------
     for ds, seed, n_iter in (("pima", 1, 40), ("australian", 2, 30), ("german", 3, 10), ("heart", 4, 24)):
         XX, t = load_csv_dataset(os.path.join(REF, "data", ds + ".csv"))
