@@ -52,6 +52,10 @@ typedef struct rmhmc_ctx rmhmc_ctx;
 #define RMHMC_FLAG_GUARDS (1u << 1)      /* RENORMALIZE guards rmhmc.py:81-85,
                                             125-130                            */
 #define RMHMC_COMPAT (RMHMC_FLAG_MOMENTUM_LT | RMHMC_FLAG_GUARDS)
+#define RMHMC_FLAG_FP32_METRIC (1u << 4) /* EXPERIMENT (BASELINE config 5 "fp32 vs fp64 tolerance sweep"): the metric
+                                            assemblies X'diag(v)X run on the fp32 matrix cores (f32 operands and
+                                            accumulators); everything else stays float64.  Not reference-compatible:
+                                            measured errors are in DESIGN.md.  Ignored by the D <= 8 fused path.      */
 #define RMHMC_FLAG_ORACLE_LITERAL (1u << 8) /* oracle only: form the DxDxD
                                                InvGdG tensor and use LU
                                                inv/solve like rmhmc.py:64-77  */

@@ -14,6 +14,7 @@ F64 = 0
 FLAG_MOMENTUM_LT = 1 << 0
 FLAG_GUARDS = 1 << 1
 COMPAT = FLAG_MOMENTUM_LT | FLAG_GUARDS
+FLAG_FP32_METRIC = 1 << 4
 FLAG_ORACLE_LITERAL = 1 << 8
 
 ST_NOT_PD, ST_NONFINITE, ST_GUARD_P, ST_GUARD_W = 1, 2, 4, 8

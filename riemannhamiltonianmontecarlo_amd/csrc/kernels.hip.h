@@ -266,6 +266,73 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2'  EXPERIMENT (RMHMC_FLAG_FP32_METRIC): the same assembly on the fp32 matrix cores, v_mfma_f32_16x16x4_f32 with f32
+// operands and accumulators (twice the fp64 rate).  Same operand maps; the f32 result map is row = 4*(lane>>4)+r.
+// colA/colB: first column of the 64-wide (or DP-wide) column block of the A and B operands; tiles I<=J only when they
+// coincide.  Used for the precision sweep of DESIGN.md, never by default.
+// ---------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int NB>
+__global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, const int* __restrict__ phase,
+                                                      const double* __restrict__ vrow, double* __restrict__ Gq, int nbk) {
+  const int DP = dd.DP;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chains) return;
+  if (phase[c] != 1) return;
+  int bA = 0, bB = 0;
+  if (nbk > 1) {  // blockIdx.y = bB(bB+1)/2 + bA
+    while ((bB + 1) * (bB + 2) / 2 <= (int)blockIdx.y) ++bB;
+    bA = blockIdx.y - bB * (bB + 1) / 2;
+  }
+  const bool diag = (bA == bB);
+  const int WB = 16 * NB;  // column block width
+  const int rr = lane >> 4, ci = lane & 15;
+  const double* __restrict__ xpA = dd.Xr + (size_t)rr * DP + WB * bA + NB * ci;
+  const double* __restrict__ xpB = dd.Xr + (size_t)rr * DP + WB * bB + NB * ci;
+  const double* __restrict__ vp = vrow + (size_t)c * dd.Mp + rr;
+  f4 acc[NB][NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int J = 0; J < NB; ++J) acc[I][J] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int n1 = 0; n1 < dd.Mp; n1 += 16)
+#pragma unroll
+  for (int n0 = n1; n0 < n1 + 16; n0 += 4) {
+    float xa[NB], xb[NB];
+    const float vv = (float)vp[n0];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      xa[I] = vv * (float)xpA[(size_t)n0 * DP + I];
+      xb[I] = (float)xpB[(size_t)n0 * DP + I];
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J)
+        if (!diag || J >= I) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[I], xb[J], acc[I][J], 0, 0, 0);
+  }
+  double* __restrict__ G = Gq + (size_t)c * DP * DP;
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      if (diag && J < I) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = WB * bA + NB * (4 * rr + r) + I;
+        const int col = WB * bB + NB * ci + J;
+        double val = (double)acc[I][J][r];
+        if (row == col) val += dd.inv_alpha;
+        if (!diag || I != J || row >= col) {
+          G[(size_t)row * DP + col] = val;
+          G[(size_t)col * DP + row] = val;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3b  fused quadratic-term pass on the matrix cores, 16 chains per wavefront:
 //        q_c[d] = sum_n c_n(w_c) (x_n.u_c)^2 x_nd  = u' dG/dw_d u      (rmhmc.py:104-107,158-161)
 // as three small GEMMs per 16 data rows:  F = X W, S = X U  (16 rows x 16 chains, K = D) and

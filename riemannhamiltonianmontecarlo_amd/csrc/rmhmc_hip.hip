@@ -180,6 +180,16 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
 
 void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
   launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
+    if (ctx->flags & RMHMC_FLAG_FP32_METRIC) {  // precision experiment: fp32 matrix cores for the metric only
+      if (ctx->big) {
+        hipLaunchKernelGGL((k_assemble_f32<4>), dim3((unsigned)((g.n + 3) / 4), ctx->npairs), dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v,
+                           g.ch.Gq, ctx->nbk);
+      } else {
+        NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble_f32<NB_>), dim3((unsigned)((g.n + 3) / 4)), dim3(256), 0, st, ctx->dd, g.n,
+                                          g.ch.phase, v, g.ch.Gq, 1));
+      }
+      return;
+    }
     if (ctx->big) {
       hipLaunchKernelGGL(k_assemble_pair<false>, dim3((unsigned)((g.n + 3) / 4), ctx->npairs - ctx->nbk), dim3(256), 0, st, ctx->dd, g.n,
                          g.ch.phase, v, g.ch.Gq);

@@ -450,3 +450,20 @@ def test_config5_shape_properties(hip, oracle):
     assert rel_err(r["w_prop"][:R], o["w_prop"]) < TOL_TRAJ
     assert rel_err(r["p_prop"][:R], o["p_prop"]) < TOL_TRAJ
     assert rel_err(r["hld_prop"][:R], o["hld_prop"]) < TOL_TRAJ
+
+
+def test_fp32_metric_experiment_flag(hip):
+    """RMHMC_FLAG_FP32_METRIC (config 5's fp32-vs-fp64 sweep, tools/fp32_sweep.py): metric assemblies on the fp32 matrix
+    cores.  Must stay close to, and be distinguishable from, the float64 path; the default must be unaffected."""
+    for M, D, n in ((2000, 24, 6), (600, 100, 3)):
+        XX, t = synthetic_logreg(M, D, 3)
+        rs = np.random.RandomState(2)
+        w = 0.05 * rs.randn(n, D); p = 10.0 * rs.randn(n, D)
+        out = []
+        for flags in (0, _capi.FLAG_FP32_METRIC, 0):
+            with hip.context(M, D, n, flags=flags) as ctx:
+                ctx.set_data(XX, t)
+                out.append(ctx.leapfrog(w, p, 0.5, 1, 1, 4))
+        assert np.array_equal(out[0][0], out[2][0])
+        e = rel_err(out[1][0], out[0][0])
+        assert 1e-10 < e < 1e-4, e
