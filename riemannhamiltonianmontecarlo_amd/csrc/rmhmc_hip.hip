@@ -778,6 +778,38 @@ int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u
 }
 
 // ---- bulk entry points --------------------------------------------------------------------------
+// The ~40 launches of one global step captured once into a hipGraph and replayed: the generic path is launch bound
+// for small batches (config 1: 0.5 ms per step of one chain, nearly all of it launch latency).  RMHMC_GRAPH=0 disables.
+struct StepGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  ~StepGraph() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+  }
+};
+static bool step_graph_usable(const rmhmc_ctx* ctx, long long nsteps) {
+  if (ctx->groups.size() != 1 || ctx->timing || nsteps < 8) return false;
+  if (ctx->fused && ctx->sampler == 0) return false;
+  if (const char* e = getenv("RMHMC_GRAPH")) return atoi(e) != 0;
+  return true;
+}
+static bool build_step_graph(rmhmc_ctx* ctx, const IterBase& ib, StepGraph& sg) {
+  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+  launch_global_step(ctx, ib);
+  if (hipStreamEndCapture(ctx->stream, &sg.graph) != hipSuccess || !sg.graph) { (void)hipGetLastError(); return false; }
+  if (hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); sg.exec = nullptr; return false; }
+  return true;
+}
+// nsteps global steps of the generic path (graph replay when it pays, plain launches otherwise)
+static void run_generic_steps(rmhmc_ctx* ctx, const IterBase& ib, long long nsteps, StepGraph* sg) {
+  if (sg && sg->exec) {
+    for (long long s = 0; s < nsteps; ++s) (void)hipGraphLaunch(sg->exec, ctx->stream);
+  } else {
+    for (long long s = 0; s < nsteps; ++s) launch_global_step(ctx, ib);
+  }
+}
+
 static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_steps) {
   // every chain needs at least min_steps more global steps; afterwards poll the done counter
   int done = 0;
@@ -798,16 +830,18 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
       if (s > min_steps * (long long)ctx->L + 1000000) return fail(ctx, RMHMC_ERR_RUNTIME, "sampler did not terminate");
     }
   }
+  StepGraph sg;
+  if (step_graph_usable(ctx, min_steps)) (void)build_step_graph(ctx, ib, sg);
+  run_generic_steps(ctx, ib, min_steps, &sg);
+  s = min_steps;
   for (;;) {
-    launch_global_step(ctx, ib);
-    ++s;
-    if (s >= min_steps && (s - min_steps) % poll == 0) {
-      join_streams(ctx);
-      HIPCK(hipMemcpyAsync(&done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      RC(sync(ctx));
-      if (done >= ctx->n) break;
-      fork_streams(ctx);
-    }
+    join_streams(ctx);
+    HIPCK(hipMemcpyAsync(&done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    RC(sync(ctx));
+    if (done >= ctx->n) break;
+    fork_streams(ctx);
+    run_generic_steps(ctx, ib, poll, &sg);
+    s += poll;
     if (s > min_steps * (long long)ctx->L + 1000000) return fail(ctx, RMHMC_ERR_RUNTIME, "sampler did not terminate");
   }
   return RMHMC_OK;
@@ -1032,8 +1066,14 @@ int rmhmc_chains_run(rmhmc_ctx* ctx, int64_t n_steps) {
   fork_streams(ctx);
   {
     Timed t(ctx, "total", ctx->stream);
-    if (ctx->fused) launch_fused(ctx, ib, n_steps);
-    else for (int64_t s = 0; s < n_steps; ++s) launch_global_step(ctx, ib);
+    if (ctx->fused) {
+      launch_fused(ctx, ib, n_steps);
+    } else {
+      StepGraph sg;
+      if (step_graph_usable(ctx, n_steps)) (void)build_step_graph(ctx, ib, sg);
+      run_generic_steps(ctx, ib, n_steps, &sg);
+      HIPCK(hipStreamSynchronize(ctx->stream));  // the graph is destroyed at the end of this scope
+    }
     join_streams(ctx);
   }
   return sync(ctx);

@@ -54,3 +54,15 @@ def test_shim_argument_checks():
         RMHMC(X, t, NumOfIterations=10, BurnIn=10)
     with pytest.raises(ValueError):
         RMHMC(X, np.zeros(4))
+
+
+def test_empty_inputs_rejected(oracle):
+    for bad in ((0, 3, 1), (10, 0, 1), (10, 3, 0)):
+        with pytest.raises(_capi.RmhmcError) as e:
+            oracle.context(*bad)
+        assert e.value.code == -1
+    with oracle.context(5, 2, 1) as ctx:
+        with pytest.raises(ValueError):
+            ctx.set_data(np.zeros((4, 2)), np.zeros(4))
+        with pytest.raises(ValueError):
+            ctx.sample(5, 5)

@@ -243,6 +243,10 @@ def test_errors(hip):
     with pytest.raises(_capi.RmhmcError) as e:
         hip.context(100, 257, 1)
     assert e.value.code == -4
+    for bad in ((0, 3, 1), (10, 0, 1), (10, 3, 0)):      # empty inputs are rejected, not silently accepted
+        with pytest.raises(_capi.RmhmcError) as e:
+            hip.context(*bad)
+        assert e.value.code == -1
     with hip.context(10, 2, 1) as ctx:
         with pytest.raises(_capi.RmhmcError):
             ctx.metric(np.zeros((1, 2)))            # set_data not called
