@@ -158,6 +158,11 @@ int rmhmc_chains_run(rmhmc_ctx *ctx, int64_t n_steps);
 /* Current position of every chain, completed transitions, accepted ones.    */
 int rmhmc_chains_state(rmhmc_ctx *ctx, double *w_out, int64_t *iters_out,
                        int64_t *accept_out);
+/* Checkpoint / resume: (w, iters, accepted) from rmhmc_chains_state is a complete checkpoint.  To resume, call
+ * rmhmc_chains_init with theta0 = the saved w (same seed, chain_offset, L, eps, K) and then this function with the
+ * saved counters.  Randomness is keyed by (seed, chain, iteration), so a chain that was in mid-trajectory replays
+ * that transition from its start and every chain continues bit for bit as if it had never stopped.          */
+int rmhmc_chains_restore(rmhmc_ctx *ctx, const int64_t *iters, const int64_t *accepted);
 /* Device seconds (HIP events on the library's stream) of the kernel named
  * `which` accumulated since the last rmhmc_chains_init, and its launch
  * count; which = "assemble" | "factor" | "momentum" | "leverage" | "total". */

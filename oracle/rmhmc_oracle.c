@@ -823,6 +823,17 @@ int rmhmc_chains_state(rmhmc_ctx *ctx, double *w_out, int64_t *iters_out, int64_
   return RMHMC_OK;
 }
 
+int rmhmc_chains_restore(rmhmc_ctx *ctx, const int64_t *iters, const int64_t *accepted) {
+  if (!ctx || !ctx->chains_ready || !iters || !accepted) return fail(ctx, RMHMC_ERR_INVALID, "chains_restore: call chains_init first");
+  for (int64_t c = 0; c < ctx->n; c++) {
+    if (iters[c] < 0 || accepted[c] < 0) return fail(ctx, RMHMC_ERR_INVALID, "chains_restore: negative counter");
+    ctx->chains[c].iter = iters[c];
+    ctx->chains[c].accepted = accepted[c];
+    ctx->chains[c].steps_left = 0;
+  }
+  return RMHMC_OK;
+}
+
 int rmhmc_kernel_time(rmhmc_ctx *ctx, const char *which, double *seconds_out, int64_t *launches_out) {
   (void)which;
   if (seconds_out) *seconds_out = 0;

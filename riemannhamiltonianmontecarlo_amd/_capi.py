@@ -45,6 +45,7 @@ SIGNATURES = {
     "rmhmc_chains_init": (C.c_int, [C.c_void_p, _dp, C.c_uint64, C.c_int64, C.c_int32, C.c_double, C.c_int32]),
     "rmhmc_chains_run": (C.c_int, [C.c_void_p, C.c_int64]),
     "rmhmc_chains_state": (C.c_int, [C.c_void_p, _dp, _lp, _lp]),
+    "rmhmc_chains_restore": (C.c_int, [C.c_void_p, _lp, _lp]),
     "rmhmc_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _lp]),
     "rmhmc_ess": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64, C.c_int32, _dp]),
     "rmhmc_sample_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
@@ -251,6 +252,11 @@ class Context:
         w = np.empty((self.n, self.D)); it = np.zeros(self.n, dtype=np.int64); acc = np.zeros(self.n, dtype=np.int64)
         self._ck(self.lib.rmhmc_chains_state(self._h, _ptr(w), _ptr(it, _lp), _ptr(acc, _lp)))
         return w, it, acc
+
+    def chains_restore(self, iters, accepted):
+        it = np.ascontiguousarray(iters, dtype=np.int64).reshape(self.n)
+        acc = np.ascontiguousarray(accepted, dtype=np.int64).reshape(self.n)
+        self._ck(self.lib.rmhmc_chains_restore(self._h, _ptr(it, _lp), _ptr(acc, _lp)))
 
     def kernel_time(self, which):
         s = C.c_double(0.0); k = C.c_int64(0)

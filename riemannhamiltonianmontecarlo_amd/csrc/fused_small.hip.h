@@ -35,6 +35,8 @@ struct FusedParams {
   int K;
   int nsteps;      // global steps to run in this launch
   int DPs;         // leading dimension of the per-chain arrays in HBM (16)
+  int init_eval;   // 1: only evaluate the record at cur.w (chain initialisation, so that every record a fused run ever
+                   //    holds comes from the same arithmetic: checkpoints resume bit for bit)
 };
 
 // ---- wave-uniform 8x8 helpers on packed lower-triangular registers -------------------------------------
@@ -374,6 +376,15 @@ __global__ __launch_bounds__(64 * FS_WAVES) void k_fused_small(DevData dd, Chain
 
   // ---- chain state -> registers -------------------------------------------------------------------------
   FsPoint trj;
+  if (fp.init_eval) {
+#pragma unroll
+    for (int d = 0; d < FS_D; ++d) trj.w[d] = (d < D) ? ch.cur.w[(size_t)c * DP + d] : 0.0;
+    const int bad = fs_eval_point(dd, Xs, ts, cbuf, lane, trj);
+    fs_store_point(ch.cur, c, D, DP, lane, trj);
+    fs_store_point(ch.trj, c, D, DP, lane, trj);
+    if (lane == 0) ch.status[c] = bad ? 1 : 0;
+    return;
+  }
   fs_load_point(ch.cur, c, DP, trj);
   fs_fix_padding(dd, trj);
   fs_point_to_lds(curL, lane, trj);

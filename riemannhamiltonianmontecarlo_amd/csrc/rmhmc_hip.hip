@@ -382,7 +382,7 @@ void launch_fused(rmhmc_ctx* ctx, const IterBase& b, long long nsteps) {
     for (Group& g : ctx->groups) {
       FusedParams fp{};
       fp.ip = iter_params(ctx, g, b);
-      fp.eps = ctx->eps; fp.K = ctx->K; fp.nsteps = chunk; fp.DPs = ctx->DP;
+      fp.eps = ctx->eps; fp.K = ctx->K; fp.nsteps = chunk; fp.DPs = ctx->DP; fp.init_eval = 0;
       launch(ctx, g, HEAVY, "fused", [&](hipStream_t st) {
         hipLaunchKernelGGL(k_fused_small, dim3((unsigned)((g.n + FS_WAVES - 1) / FS_WAVES)), dim3(64 * FS_WAVES), ctx->fused_lds, st,
                            ctx->dd, g.ch, fp);
@@ -724,8 +724,22 @@ static int init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] or NU
     th.assign((size_t)ctx->n * ctx->D, 1e-3);  // rmhmc.py:27
     theta0_host = th.data();
   }
-  RC(eval_at(ctx, theta0_host, nullptr));
-  for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_commit_all, ctx->D, ctx->DP, g.ch);
+  if (ctx->fused) {  // the fused path evaluates its own initial record (same arithmetic as inside its steps)
+    RC(upload_vec(ctx, ctx->ch.cur.w, theta0_host));
+    fork_streams(ctx);
+    for (Group& g : ctx->groups) {
+      FusedParams fp{};
+      fp.ip = iter_params(ctx, g, IterBase{0, 0, 0, nullptr, false, false});
+      fp.eps = ctx->eps; fp.K = ctx->K; fp.nsteps = 0; fp.DPs = ctx->DP; fp.init_eval = 1;
+      launch(ctx, g, HEAVY, "fused", [&](hipStream_t st) {
+        hipLaunchKernelGGL(k_fused_small, dim3((unsigned)((g.n + FS_WAVES - 1) / FS_WAVES)), dim3(64 * FS_WAVES), ctx->fused_lds, st,
+                           ctx->dd, g.ch, fp);
+      });
+    }
+  } else {
+    RC(eval_at(ctx, theta0_host, nullptr));
+    for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_commit_all, ctx->D, ctx->DP, g.ch);
+  }
   join_streams(ctx);
   fill_int(ctx, ctx->ch.phase, 0, ctx->n);
   fill_int(ctx, ctx->ch.steps_left, 0, ctx->n);
@@ -1086,6 +1100,16 @@ int rmhmc_chains_state(rmhmc_ctx* ctx, double* w_out, int64_t* iters_out, int64_
   static_assert(sizeof(long long) == sizeof(int64_t), "int64");
   if (iters_out) RC(download(ctx, (long long*)iters_out, ctx->ch.iter, ctx->n));
   if (accept_out) RC(download(ctx, (long long*)accept_out, ctx->ch.accepted, ctx->n));
+  return sync(ctx);
+}
+
+int rmhmc_chains_restore(rmhmc_ctx* ctx, const int64_t* iters, const int64_t* accepted) {
+  NEED_DATA(ctx);
+  if (!ctx->chains_ready || !iters || !accepted) return fail(ctx, RMHMC_ERR_INVALID, "chains_restore: call rmhmc_chains_init first");
+  for (int64_t c = 0; c < ctx->n; ++c)
+    if (iters[c] < 0 || accepted[c] < 0) return fail(ctx, RMHMC_ERR_INVALID, "chains_restore: negative counter");
+  RC(upload(ctx, ctx->ch.iter, (const long long*)iters, ctx->n));
+  RC(upload(ctx, ctx->ch.accepted, (const long long*)accepted, ctx->n));
   return sync(ctx);
 }
 

@@ -471,3 +471,10 @@ def test_fp32_metric_experiment_flag(hip):
         assert np.array_equal(out[0][0], out[2][0])
         e = rel_err(out[1][0], out[0][0])
         assert 1e-10 < e < 1e-4, e
+
+
+def test_checkpoint_resume(hip):
+    """SURVEY section 5 (checkpoint / resume): bit-exact continuation from (w, iters, accepted), fused and generic paths."""
+    from test_oracle_golden import _checkpoint_resume_check
+    _checkpoint_resume_check(hip, M=150, D=6, n=4)      # fused small-problem kernel
+    _checkpoint_resume_check(hip, M=150, D=12, n=3)     # generic kernels

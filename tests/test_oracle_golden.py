@@ -174,3 +174,41 @@ def test_chains_api_equals_sample(oracle):
         k = min(len(seen[c]), 8)
         assert k >= 6
         assert np.allclose(np.array(seen[c][:k]), s[c, :k], rtol=0, atol=0)
+
+
+def _checkpoint_resume_check(lib, M=150, D=6, n=4):
+    """(w, iters, accepted) is a complete checkpoint: a resumed run visits exactly the states of an uninterrupted one."""
+    from riemannhamiltonianmontecarlo_amd.data import synthetic_logreg
+    XX, t = synthetic_logreg(M, D, 5)
+
+    def visited(ctx, steps, seen, last):
+        for _ in range(steps):
+            ctx.chains_run(1)
+            w, it, a = ctx.chains_state()
+            for c in range(n):
+                if it[c] > last[c]:
+                    seen[c][int(it[c])] = w[c].copy(); last[c] = it[c]
+        return ctx.chains_state()
+
+    with lib.context(M, D, n) as ctx:                       # uninterrupted
+        ctx.set_data(XX, t); ctx.chains_init(seed=12, L=4)
+        ref = [dict() for _ in range(n)]
+        visited(ctx, 40, ref, np.zeros(n, dtype=np.int64))
+    got = [dict() for _ in range(n)]
+    last = np.zeros(n, dtype=np.int64)
+    with lib.context(M, D, n) as ctx:                       # first half, checkpoint in mid-trajectory for some chains
+        ctx.set_data(XX, t); ctx.chains_init(seed=12, L=4)
+        w, it, acc = visited(ctx, 17, got, last)
+    with lib.context(M, D, n) as ctx:                       # resume in a fresh context
+        ctx.set_data(XX, t); ctx.chains_init(theta0=w, seed=12, L=4); ctx.chains_restore(it, acc)
+        last = it.copy()
+        visited(ctx, 40, got, last)
+    for c in range(n):
+        common = sorted(set(ref[c]) & set(got[c]))
+        assert len(common) >= 8
+        for k in common:
+            assert np.array_equal(ref[c][k], got[c][k]), (c, k)
+
+
+def test_checkpoint_resume_oracle(oracle):
+    _checkpoint_resume_check(oracle)
