@@ -50,7 +50,7 @@ def load_problem(name):
     return synthetic_logreg(wl["M"], wl["D"], 0)
 
 
-def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0):
+def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0, literal_budget_s=10.0):
     """Time the CPU oracle (oracle/librmhmc_oracle.so, the C restatement of rmhmc.py — kind "port") on
     the host cores with a bounded sample of the same workload: `cores` chains, a few global steps."""
     from riemannhamiltonianmontecarlo_amd import _capi
@@ -76,9 +76,21 @@ def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0):
         grow /= new_steps / steps
         steps = new_steps
         n = int(min(8192, max(n, int(n * grow) // cores * cores)))
-    return {"value": n * steps / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d chains x %d leapfrog steps of the same (M=%d, D=%d) workload, matrix-free C oracle, OpenMP over chains, %.1f s"
-                      % (n, steps, M, D, dt)}
+    out = {"value": n * steps / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+           "sample": "%d chains x %d leapfrog steps of the same (M=%d, D=%d) workload, matrix-free C oracle, OpenMP over chains, %.1f s"
+                     % (n, steps, M, D, dt)}
+    # the reference's own O(M D^3) formulation (forms the DxDxD tensor, LU inverse/solve: the literal variant of the
+    # oracle, i.e. what code/rmhmc.py does, in C instead of NumPy) on a smaller sample, for an apples-to-apples number
+    if literal_budget_s > 0 and D <= 64:
+        rs = np.random.RandomState(0)
+        w = np.full((cores, D), 1e-3); p = rs.randn(cores, D)
+        with oracle.context(M, D, cores, flags=flags | _capi.FLAG_ORACLE_LITERAL) as ctx:
+            ctx.set_data(XX, t)
+            t0 = time.perf_counter(); ctx.leapfrog(w, p, eps, 1, 1, K); dtl = time.perf_counter() - t0
+        out["reference_algorithm"] = {"value": cores / dtl, "unit": "leapfrog-steps/s", "cores": cores,
+                                      "sample": "%d chains x 1 leapfrog step incl. the set-up block (rmhmc.py:50-77), literal "
+                                                "tensor-forming C restatement of rmhmc.py, %.1f s" % (cores, dtl)}
+    return out
 
 
 def main():
