@@ -208,6 +208,19 @@ int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t 
                        double *var_out, double *ess_out, int64_t *accept_out, int64_t *steps_out,
                        double *seconds_out);
 
+/* ---- widening, SURVEY.md 8(f)-4: simplified manifold MALA ---------------------------------------------
+ * authors_code/Bayes_Log_Reg/MCMC/BLR_mMALA_Simp.m:175-290 (MATLAB only: the Python reference has no mMALA and no
+ * MATLAB/Octave runs here, so this row has NO executable reference: "parity unpinned"; the GPU path is checked against
+ * the oracle's restatement of the .m file and statistically against RMHMC and the paper's Table 3).
+ *   proposal  w' = w + eps/2 G^-1 grad + N(0, eps G^-1)        (:217-219, eps = StepSize = 1)
+ *   accept    LJL' + log q(w|w') - LJL - log q(w'|w)             (:227-254)
+ * Uses the metric / gradient / Cholesky kernels of the RMHMC path; one point evaluation per transition.   */
+int rmhmc_mmala_transition(rmhmc_ctx *ctx, double *w, const double *z, const double *u_acc, double eps,
+                           int32_t *accepted_out, double *ratio_out, double *w_prop_out);
+int rmhmc_mmala_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, double eps, uint64_t seed,
+                       int64_t chain_offset, const double *theta0, double *samples_out,
+                       int64_t *accept_out, double *seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

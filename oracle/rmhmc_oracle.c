@@ -1001,6 +1001,106 @@ int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t 
   return rc;
 }
 
+/* ------------------------------------------------------------------------ */
+/* simplified manifold MALA: restatement of BLR_mMALA_Simp.m:175-290          */
+/* ------------------------------------------------------------------------ */
+typedef struct { double *w, *grad, *G, *L, *Ginv; double ljl, hld; } mpoint_t;
+static void mpoint_alloc(int D, mpoint_t *q) {
+  q->w = (double *)calloc(D, sizeof(double)); q->grad = (double *)calloc(D, sizeof(double));
+  q->G = (double *)calloc((size_t)D * D, sizeof(double)); q->L = (double *)calloc((size_t)D * D, sizeof(double));
+  q->Ginv = (double *)calloc((size_t)D * D, sizeof(double));
+}
+static void mpoint_free(mpoint_t *q) { free(q->w); free(q->grad); free(q->G); free(q->L); free(q->Ginv); }
+static void mpoint_eval(const rmhmc_ctx *c, mpoint_t *q, double *tmp) {  /* BLR_mMALA_Simp.m:186-199,229-243 */
+  metric(c, q->w, q->G, NULL);
+  chol_lower(c->D, q->G, q->L);
+  q->hld = half_logdet(c->D, q->L);
+  chol_inverse(c->D, q->L, q->Ginv, tmp);
+  gradient(c, q->w, q->grad);
+  q->ljl = log_joint(c, q->w);
+}
+static void mpoint_copy(int D, mpoint_t *d, const mpoint_t *s) {
+  memcpy(d->w, s->w, sizeof(double) * D); memcpy(d->grad, s->grad, sizeof(double) * D);
+  memcpy(d->G, s->G, sizeof(double) * D * D); memcpy(d->L, s->L, sizeof(double) * D * D); memcpy(d->Ginv, s->Ginv, sizeof(double) * D * D);
+  d->ljl = s->ljl; d->hld = s->hld;
+}
+/* one transition; cur in/out (replaced on acceptance); returns accepted */
+static int mmala_transition(const rmhmc_ctx *c, mpoint_t *cur, mpoint_t *prop, const double *z, double u_acc, double eps,
+                            double *a, double *b, double *ratio_out) {
+  const int D = c->D;
+  /* drift and proposal (:217-219): w' = w + eps/2 G^-1 grad + sqrt(eps) L^-T z, i.e. N(mean, eps G^-1); L^-T z = G^-1 (L z) */
+  matvec(D, cur->Ginv, cur->grad, a);
+  for (int i = 0; i < D; i++) { double s = 0; for (int j = 0; j <= i; j++) s += cur->L[i * D + j] * z[j]; b[i] = s; }
+  for (int i = 0; i < D; i++) prop->w[i] = cur->w[i] + 0.5 * eps * a[i];
+  matvec(D, cur->Ginv, b, a);
+  for (int i = 0; i < D; i++) prop->w[i] += sqrt(eps) * a[i];
+  /* log q(w'|w) up to the constant -(D/2) log eps shared by both directions (:227): (w'-mean)'(G/eps)(w'-mean) = z'z */
+  const double q_fwd = cur->hld - 0.5 * dot(D, z, z);
+  mpoint_eval(c, prop, a);
+  /* log q(w|w') (:245-247) */
+  matvec(D, prop->Ginv, prop->grad, a);
+  for (int i = 0; i < D; i++) b[i] = prop->w[i] + 0.5 * eps * a[i] - cur->w[i];
+  double yy = 0;
+  for (int j = 0; j < D; j++) { double s = 0; for (int i = j; i < D; i++) s += prop->L[i * D + j] * b[i]; yy += s * s; } /* |L'^T d|^2 = d'G'd */
+  const double q_rev = prop->hld - yy / (2.0 * eps);
+  const double ratio = prop->ljl + q_rev - cur->ljl - q_fwd; /* :251 */
+  if (ratio_out) *ratio_out = ratio;
+  const int acc = (ratio > 0) || (ratio > log(u_acc));
+  if (acc) mpoint_copy(D, cur, prop);
+  return acc;
+}
+
+int rmhmc_mmala_transition(rmhmc_ctx *ctx, double *w, const double *z, const double *u_acc, double eps, int32_t *accepted_out,
+                           double *ratio_out, double *w_prop_out) {
+  NEED_DATA(ctx);
+  const int D = ctx->D;
+#pragma omp parallel for schedule(dynamic)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    mpoint_t cur, prop; mpoint_alloc(D, &cur); mpoint_alloc(D, &prop);
+    double *a = (double *)calloc(D, sizeof(double)), *b = (double *)calloc(D, sizeof(double)), r;
+    memcpy(cur.w, &w[c * D], sizeof(double) * D);
+    mpoint_eval(ctx, &cur, a);
+    const int acc = mmala_transition(ctx, &cur, &prop, &z[c * D], u_acc[c], eps, a, b, &r);
+    memcpy(&w[c * D], cur.w, sizeof(double) * D);
+    if (accepted_out) accepted_out[c] = acc;
+    if (ratio_out) ratio_out[c] = r;
+    if (w_prop_out) memcpy(&w_prop_out[c * D], prop.w, sizeof(double) * D);
+    free(a); free(b); mpoint_free(&cur); mpoint_free(&prop);
+  }
+  return RMHMC_OK;
+}
+
+int rmhmc_mmala_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, double eps, uint64_t seed, int64_t chain_offset,
+                       const double *theta0, double *samples_out, int64_t *accept_out, double *seconds_out) {
+  NEED_DATA(ctx);
+  if (burn_in >= n_iter || burn_in < 0 || !(eps > 0)) return fail(ctx, RMHMC_ERR_INVALID, "need 0 <= burn_in < n_iter, eps > 0");
+  const int D = ctx->D;
+  const int64_t S = n_iter - burn_in;
+  double t_post = 0;
+#pragma omp parallel for schedule(dynamic) reduction(max : t_post)
+  for (int64_t c = 0; c < ctx->n; c++) {
+    mpoint_t cur, prop; mpoint_alloc(D, &cur); mpoint_alloc(D, &prop);
+    double *a = (double *)calloc(D, sizeof(double)), *b = (double *)calloc(D, sizeof(double)), *z = (double *)calloc(D + 1, sizeof(double));
+    for (int d = 0; d < D; d++) cur.w[d] = theta0 ? theta0[c * D + d] : 0.0; /* BLR_mMALA_Simp.m:175 */
+    mpoint_eval(ctx, &cur, a);
+    int64_t acc = 0;
+    double t0 = 0;
+    for (int64_t it = 0; it < n_iter; it++) {
+      double u_len, g_dir, u_acc;
+      rng_draws(seed, (uint64_t)(chain_offset + c), (uint32_t)it, D, z, &u_len, &g_dir, &u_acc);
+      acc += mmala_transition(ctx, &cur, &prop, z, u_acc, eps, a, b, NULL);
+      if (it >= burn_in) memcpy(&samples_out[(c * S + (it - burn_in)) * D], cur.w, sizeof(double) * D);
+      if (it == burn_in) t0 = now_s();
+    }
+    const double dt = now_s() - t0;
+    if (dt > t_post) t_post = dt;
+    if (accept_out) accept_out[c] = acc;
+    free(a); free(b); free(z); mpoint_free(&cur); mpoint_free(&prop);
+  }
+  if (seconds_out) *seconds_out = t_post;
+  return RMHMC_OK;
+}
+
 void rmhmc_destroy(rmhmc_ctx *ctx) {
   if (!ctx) return;
   if (ctx->chains) {

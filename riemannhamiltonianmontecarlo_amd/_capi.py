@@ -50,6 +50,8 @@ SIGNATURES = {
     "rmhmc_ess": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64, C.c_int32, _dp]),
     "rmhmc_sample_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                      _dp, _dp, _dp, _dp, _lp, _lp, _dp]),
+    "rmhmc_mmala_transition": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_double, _ip, _dp, _dp]),
+    "rmhmc_mmala_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_uint64, C.c_int64, _dp, _dp, _lp, _dp]),
     "rmhmc_hmc_transition": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, _ip, _ip, _dp, _dp, _dp, _dp]),
     "rmhmc_hmc_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_int64, _dp, _dp,
                                    _lp, _lp, _dp]),
@@ -216,6 +218,25 @@ class Context:
                                              int(chain_offset), _ptr(th), _ptr(mean), _ptr(var), _ptr(ess), _ptr(acc, _lp),
                                              _ptr(steps, _lp), C.cast(C.byref(secs), _dp)))
         return dict(mean=mean, var=var, ess=ess, accepted=acc, leapfrog_steps=steps, seconds=secs.value)
+
+    # ---- simplified mMALA (authors_code/.../BLR_mMALA_Simp.m) -------------------
+    def mmala_transition(self, w, z, u_acc, eps=1.0):
+        n, D = self.n, self.D
+        w = _f64(w, (n, D)).copy(); z = _f64(z, (n, D)); u_acc = _f64(u_acc, (n,))
+        acc = np.zeros(n, dtype=np.int32); ratio = np.empty(n); wp = np.empty((n, D))
+        self._ck(self.lib.rmhmc_mmala_transition(self._h, _ptr(w), _ptr(z), _ptr(u_acc), float(eps), _ptr(acc, _ip), _ptr(ratio), _ptr(wp)))
+        return dict(w=w, accepted=acc, ratio=ratio, w_prop=wp)
+
+    def mmala_sample(self, n_iter, burn_in, eps=1.0, seed=0, chain_offset=0, theta0=None):
+        n, D = self.n, self.D
+        S = int(n_iter) - int(burn_in)
+        if S <= 0:
+            raise ValueError("BurnIn must be < NumOfIterations")
+        th = None if theta0 is None else _f64(np.broadcast_to(theta0, (n, D)))
+        samples = np.empty((n, S, D)); acc = np.zeros(n, dtype=np.int64); secs = C.c_double(0.0)
+        self._ck(self.lib.rmhmc_mmala_sample(self._h, int(n_iter), int(burn_in), float(eps), int(seed), int(chain_offset), _ptr(th),
+                                             _ptr(samples), _ptr(acc, _lp), C.cast(C.byref(secs), _dp)))
+        return samples, acc, secs.value
 
     # ---- plain HMC (code/hmc.py) ---------------------------------------------
     def hmc_transition(self, w, z, u_len, u_acc, L=100, eps=0.14):

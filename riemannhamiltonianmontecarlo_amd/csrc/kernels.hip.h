@@ -1101,6 +1101,106 @@ __global__ __launch_bounds__(64) void k_hmc_end(int D, int DP, Chains ch, IterPa
 }
 
 // ---------------------------------------------------------------------------------------------
+// simplified manifold MALA (widening row 8f-4; authors_code/Bayes_Log_Reg/MCMC/BLR_mMALA_Simp.m:175-290): one point
+// evaluation per transition with the RMHMC kernels, proposal and acceptance here.  Every chain does one transition
+// per step, so there is no asynchronous bookkeeping.  Hcur carries LJL + log q(w'|w) of the current transition.
+// ---------------------------------------------------------------------------------------------
+// proposal w' = w + eps/2 G^-1 grad + sqrt(eps) G^-1 (L z)  ( = N(mean, eps G^-1), :217-219 )  ->  trj.w
+__global__ __launch_bounds__(64) void k_mmala_begin(int D, int DP, Chains ch, IterParams ip, double eps) {
+  __shared__ double zs[RM_DMAX];
+  __shared__ double ts[RM_DMAX];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const long long it = ch.iter[c];
+  if (it >= ip.iter_limit) { if (lane == 0) ch.phase[c] = 0; return; }
+  draw_normals(ip, c, it, D, lane, zs);
+  const double* __restrict__ Lc = ch.cur.L + (size_t)c * DP * DP;
+  const double* __restrict__ Gi = ch.cur.Ginv + (size_t)c * DP * DP;
+  double zz = 0.0;
+  for (int d = lane; d < D; d += 64) {  // t = L z + sqrt(eps)/2 ... : ts = sqrt(eps) L z + eps/2 grad, then w' = w + Ginv ts
+    double s = 0.0;
+    for (int j = 0; j <= d; ++j) s = fma(Lc[(size_t)d * DP + j], zs[j], s);
+    ts[d] = sqrt(eps) * s + 0.5 * eps * ch.cur.grad[(size_t)c * DP + d];
+    zz = fma(zs[d], zs[d], zz);
+  }
+  zz = wave_sum(zz);
+  __syncthreads();
+  double u[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = 0; j < D; ++j) {
+    const double tj = ts[j];
+#pragma unroll
+    for (int k = 0; k < RM_DCH; ++k) {
+      const int d = lane + 64 * k;
+      if (d < D) u[k] = fma(Gi[(size_t)j * DP + d], tj, u[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RM_DCH; ++k) {
+    const int d = lane + 64 * k;
+    if (d < D) ch.trj.w[(size_t)c * DP + d] = ch.cur.w[(size_t)c * DP + d] + u[k];
+  }
+  if (lane == 0) {
+    ch.Hcur[c] = ch.cur.ljl[c] + ch.cur.hld[c] - 0.5 * zz;  // LJL + log q(w'|w)  (:227, constant -(D/2) log eps dropped)
+    ch.status[c] = 0;
+    ch.phase[c] = 1;
+  }
+}
+// acceptance (:229-262) once the record at w' has been evaluated
+__global__ __launch_bounds__(64) void k_mmala_end(int D, int DP, Chains ch, IterParams ip, double eps) {
+  __shared__ double ds[RM_DMAX];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  const long long it = ch.iter[c];
+  const double* __restrict__ Lp = ch.trj.L + (size_t)c * DP * DP;
+  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  // d = w' + eps/2 G'^-1 grad' - w
+  double u[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = 0; j < D; ++j) {
+    const double gj = ch.trj.grad[(size_t)c * DP + j];
+#pragma unroll
+    for (int k = 0; k < RM_DCH; ++k) {
+      const int d = lane + 64 * k;
+      if (d < D) u[k] = fma(Gi[(size_t)j * DP + d], gj, u[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RM_DCH; ++k) {
+    const int d = lane + 64 * k;
+    if (d < D) ds[d] = ch.trj.w[(size_t)c * DP + d] + 0.5 * eps * u[k] - ch.cur.w[(size_t)c * DP + d];
+  }
+  __syncthreads();
+  // |L'^T d|^2 = d' G' d
+  double yy = 0.0;
+  for (int j = lane; j < D; j += 64) {
+    double s = 0.0;
+    for (int i = j; i < D; ++i) s = fma(Lp[(size_t)i * DP + j], ds[i], s);
+    yy = fma(s, s, yy);
+  }
+  yy = wave_sum(yy);
+  const double q_rev = ch.trj.hld[c] - yy / (2.0 * eps);
+  const double ratio = ch.trj.ljl[c] + q_rev - ch.Hcur[c];  // :251
+  double u_acc;
+  if (ip.z_in) {
+    u_acc = ip.uacc_in[c];
+  } else {
+    double U0;
+    rng_block(ip.seed, (unsigned long long)(ip.chain_offset + c), (uint32_t)it, 0x40000000u, U0, u_acc);
+  }
+  const bool accept = (ratio > 0.0) || (ratio > log(u_acc));
+  __syncthreads();
+  if (accept) copy_rec(ch.cur, ch.trj, c, D, DP, lane);
+  __syncthreads();
+  if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S)
+    for (int d = lane; d < D; d += 64)
+      ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + d] = ch.cur.w[(size_t)c * DP + d];
+  if (lane == 0) {
+    ch.Hprop[c] = ratio;
+    if (accept) ch.accepted[c] += 1;
+    ch.iter[c] = it + 1;
+    ch.phase[c] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ESS on the device (widening row 8f-2): tools.CalculateESS(Samples, S-1), tools.py:32-74, for one series per
 // wavefront.  samples[(c*S + s)*P + d]; the centred series lives in LDS; autocovariances are evaluated lag by lag
 // (two per Geyer pair, tools.py:46-50) until the running-minimum pair sum (:54-60) turns non-positive, which is

@@ -259,7 +259,7 @@ void run_phases(rmhmc_ctx* ctx, const std::vector<Phase>& phases) {
 // Evaluate the point record at trj.w for every chain in phase 1 (rmhmc.py:134-161; with advance the
 // explicit momentum half step :163 too): v, r, c, log-joint partials -> G and gradient on the matrix cores
 // -> factor / inverse / u = G^-1 p -> quadratic term -> leverage pass (trace term) -> momentum update.
-void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance) {
+void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, bool metric_only = false) {
   ph.push_back([ctx](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv2); });
   if (ctx->big) ph.push_back([ctx](Group& g) { SMALL(ctx, g, "small", k_finish_big, ctx->dd, g.ch, g.nsplit); });
   ph.push_back([ctx](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
@@ -275,6 +275,7 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance) {
   } else {
     ph.push_back([ctx](Group& g) { SMALL(ctx, g, "factor", k_factor_full, ctx->dd, g.ch, g.nsplit); });
   }
+  if (metric_only) return;  // simplified mMALA needs neither the quadratic nor the trace term
   ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
   ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
   ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
@@ -1061,6 +1062,83 @@ int rmhmc_hmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L,
   }();
   (void)hipFree(d_samples);
   ctx->sampler = 0;
+  return rc;
+}
+
+// ---- simplified manifold MALA (BLR_mMALA_Simp.m) -------------------------------------------------------------
+static void launch_mmala_step(rmhmc_ctx* ctx, const IterBase& b) {
+  std::vector<Phase> ph;
+  const double eps = ctx->eps;
+  ph.push_back([ctx, b, eps](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_mmala_begin, ctx->D, ctx->DP, g.ch, ip, eps); });
+  eval_point_phases(ctx, ph, false, true);
+  ph.push_back([ctx, b, eps](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_mmala_end, ctx->D, ctx->DP, g.ch, ip, eps); });
+  run_phases(ctx, ph);
+}
+// record at theta0 (generic kernels; mMALA never uses the fused stepping kernel)
+static int mmala_init(rmhmc_ctx* ctx, const double* theta0_host) {
+  std::vector<double> th;
+  if (!theta0_host) { th.assign((size_t)ctx->n * ctx->D, 0.0); theta0_host = th.data(); }  // BLR_mMALA_Simp.m:175
+  const bool fused = ctx->fused;
+  ctx->fused = false;
+  const int rc = init_chains(ctx, theta0_host);
+  ctx->fused = fused;
+  return rc;
+}
+
+int rmhmc_mmala_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u_acc, double eps, int32_t* accepted_out,
+                           double* ratio_out, double* w_prop_out) {
+  NEED_DATA(ctx);
+  if (!w || !z || !u_acc || !(eps > 0)) return fail(ctx, RMHMC_ERR_INVALID, "mmala_transition: null pointer or eps <= 0");
+  ctx->chains_ready = false;
+  ctx->eps = eps;
+  RC(mmala_init(ctx, w));
+  RC(upload(ctx, ctx->d_z, z, (size_t)ctx->n * ctx->D));
+  RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
+  const IterBase ib{1, 0, 0, nullptr, true, false};
+  fork_streams(ctx);
+  launch_mmala_step(ctx, ib);
+  join_streams(ctx);
+  std::vector<long long> acc(ctx->n);
+  RC(download_vec(ctx, w, ctx->ch.cur.w));
+  RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
+  if (ratio_out) RC(download(ctx, ratio_out, ctx->ch.Hprop, ctx->n));
+  if (w_prop_out) RC(download_vec(ctx, w_prop_out, ctx->ch.trj.w));
+  RC(sync(ctx));
+  if (accepted_out) for (int64_t c = 0; c < ctx->n; ++c) accepted_out[c] = (int32_t)acc[c];
+  return RMHMC_OK;
+}
+
+int rmhmc_mmala_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, double eps, uint64_t seed, int64_t chain_offset,
+                       const double* theta0, double* samples_out, int64_t* accept_out, double* seconds_out) {
+  NEED_DATA(ctx);
+  if (!samples_out || burn_in < 0 || burn_in >= n_iter || !(eps > 0))
+    return fail(ctx, RMHMC_ERR_INVALID, "mmala_sample: need samples_out, 0 <= burn_in < n_iter, eps > 0");
+  ctx->chains_ready = false;
+  ctx->eps = eps; ctx->seed = seed; ctx->chain_offset = chain_offset;
+  const long long S = n_iter - burn_in;
+  double* d_samples = nullptr;
+  HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
+  int rc = [&]() -> int {
+    RC(mmala_init(ctx, theta0));
+    const IterBase ib{n_iter, burn_in, S, d_samples, false, false};
+    fork_streams(ctx);
+    for (int64_t it = 0; it <= burn_in; ++it) launch_mmala_step(ctx, ib);
+    join_streams(ctx);
+    RC(sync(ctx));
+    const auto t0 = std::chrono::steady_clock::now();
+    fork_streams(ctx);
+    for (int64_t it = burn_in + 1; it < n_iter; ++it) launch_mmala_step(ctx, ib);
+    join_streams(ctx);
+    RC(sync(ctx));
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D, hipMemcpyDeviceToHost, ctx->stream));
+    if (accept_out) {
+      static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+      RC(download(ctx, (long long*)accept_out, ctx->ch.accepted, ctx->n));
+    }
+    return sync(ctx);
+  }();
+  (void)hipFree(d_samples);
   return rc;
 }
 
