@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md (spec; 6.3e12 achievable, 5.94e12 measured by tools/mfma_probe)
+INT8_MFMA_PEAK = 5.0e15   # op/s dense int8 matrix (2x the bf16 rate, MI355X_MICROARCH.md)
 FP64_MFMA_PEAK = 78.6e12  # flop/s dense fp64 matrix (spec); tools/mfma_probe measures 75.1e12
 
 WORKLOADS = {
@@ -100,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--i8-slices", type=int, default=0, help="4..7: assemble the metric on the int8 matrix cores from that many exact byte "
+                    "slices per operand (RMHMC_FLAG_INT8_METRIC, D <= 64); 0: fp64 matrix cores")
     ap.add_argument("--compat", type=int, default=0, help="1: reference-compatible momentum (L'z) and guards; 0: corrected (default, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ess-iters", type=int, default=0,
@@ -136,9 +139,10 @@ def main():
     M, D = XX.shape
     L, eps, K = 6, 0.5, 4  # reference defaults, rmhmc.py:13
     flags = _capi.COMPAT if args.compat else 0
+    gpu_flags = flags | (_capi.int8_metric_flags(args.i8_slices) if args.i8_slices else 0)
 
     lib = _capi.load_hip_library()  # raises if the extension is not built
-    ctx = lib.context(M, D, n, flags=flags, device=dev)
+    ctx = lib.context(M, D, n, flags=gpu_flags, device=dev)
     ctx.set_data(XX, t)
     ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
 
@@ -162,7 +166,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kt = {k: ctx.kernel_time(k) for k in ("assemble", "leverage", "rowpass", "mompass", "factor", "small", "fused", "total")}
+    kt = {k: ctx.kernel_time(k) for k in ("assemble", "assemble_i8", "vsplit", "leverage", "rowpass", "mompass", "factor", "small", "fused", "total")}
     ctx.kernel_time("disable")
     w_end, iters, acc = ctx.chains_state()
     finite = bool(np.isfinite(w_end).all())
@@ -217,6 +221,23 @@ def main():
                     "note": "achieved = algorithmic bytes (80*M*D per chain per leapfrog step, SURVEY 8(d)) / measured launch time; "
                             "X (64 KB at config 2) is loaded into LDS once per launch, so real HBM traffic is ~0 and the kernel is "
                             "bound by fp64 VALU issue and exp/log latency, not by HBM"}
+        elif kt["assemble_i8"][1] > 0:
+            # int8 metric path: the assembly is a sliced integer GEMM, S(S+1)/2 byte products per fp64 product
+            S = args.i8_slices
+            i_s, i_n = kt["assemble_i8"]
+            i_avg = i_s / i_n
+            NP = D * (D + 1) // 2
+            ops = 2.0 * n * M * NP * (S * (S + 1) // 2)
+            roof = {"bound": "mfma", "kernel": "k_assemble_i8 (sum_n v_n x_na x_nb as a sliced int8 GEMM, %d slices, v_mfma_i32_32x32x32_i8)" % S,
+                    "achieved": ops / i_avg / 1e12, "peak": INT8_MFMA_PEAK / 1e12, "unit": "TOP/s", "frac": ops / i_avg / INT8_MFMA_PEAK,
+                    "traffic": None, "avg_launch_ms": i_avg * 1e3, "launches": i_n,
+                    "fp64_equivalent_tflops": 2.0 * n * M * NP / i_avg / 1e12,
+                    "fp64_equivalent_frac_of_fp64_mfma_peak": 2.0 * n * M * NP / i_avg / FP64_MFMA_PEAK,
+                    "vsplit_avg_launch_ms": kt["vsplit"][0] / max(1, kt["vsplit"][1]) * 1e3,
+                    "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
+                    "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
+                    "note": "achieved = int8 multiply-adds issued for the unpadded problem (chains x D(D+1)/2 pairs x M rows x S(S+1)/2 "
+                            "slice products) / measured launch time; fp64_equivalent = the fp64 flops of the same assembly"}
         elif a_n > 0:
             a_avg = a_s / a_n
             achieved = pass_bytes / a_avg
@@ -250,7 +271,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
                        "D": D, "M": M, "leapfrog_L": L, "step_size": eps, "fixed_point_K": K,
-                       "compat": bool(args.compat), "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
+                       "compat": bool(args.compat), "metric_assembly": ("int8 x %d slices" % args.i8_slices) if args.i8_slices else "fp64", "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "roofline": roof,
             "kernel_seconds": {k: {"seconds": v[0], "launches": v[1]} for k, v in kt.items()},
             "all_finite": finite, "acceptance_rate": acc_rate,

@@ -15,6 +15,14 @@ FLAG_MOMENTUM_LT = 1 << 0
 FLAG_GUARDS = 1 << 1
 COMPAT = FLAG_MOMENTUM_LT | FLAG_GUARDS
 FLAG_FP32_METRIC = 1 << 4
+FLAG_INT8_METRIC = 1 << 5
+
+
+def int8_metric_flags(slices=6):
+    """flags for the int8 matrix-core metric assembly with `slices` byte slices per operand (4..7), include/rmhmc.h"""
+    if not 4 <= int(slices) <= 7:
+        raise ValueError("slices must be 4..7")
+    return FLAG_INT8_METRIC | (int(slices) << 12)
 FLAG_ORACLE_LITERAL = 1 << 8
 
 ST_NOT_PD, ST_NONFINITE, ST_GUARD_P, ST_GUARD_W = 1, 2, 4, 8

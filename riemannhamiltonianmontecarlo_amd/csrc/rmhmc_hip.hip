@@ -9,6 +9,7 @@
 #include "kernels.hip.h"
 #include "fused_small.hip.h"
 #include "large_d.hip.h"
+#include "metric_i8.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -39,6 +40,9 @@ struct Group {
   std::vector<hipEvent_t> ring;
   size_t ring_pos = 0;
   int prev = -1;  // stream of the group's previous launch: 0 main, 1 side, -1 none since the last fork
+  int8_t* Vs = nullptr;  // int8 metric path: slices of v, [S][nks][nCp][32]
+  int* vbad = nullptr;
+  int nCp = 0;
 };
 
 enum Cls { HEAVY = 0, LIGHT = 1 };
@@ -65,6 +69,12 @@ struct rmhmc_ctx {
   bool want_G = false;
   bool fused = false;        // small-problem path: D <= 8 and X fits in LDS (fused_small.hip.h)
   size_t fused_lds = 0;
+  // int8 metric path (metric_i8.hip.h)
+  bool i8 = false;
+  int i8S = 0, i8_nks = 0, i8_bn = 128;
+  int8_t* d_Zs = nullptr;
+  int* d_ze = nullptr;
+  I8Pairs pairs{};
   // sampler parameters of the stateful API
   int L = 6, K = 4;
   double eps = 0.5;
@@ -178,7 +188,32 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
   });
 }
 
+// int8 metric path: cut v into slices, then the sliced GEMM against the fixed slices of x_a x_b (metric_i8.hip.h)
+template <int S, int WN, int TN>
+void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part) {
+  if (part == 0) {
+    hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)g.n), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad);
+    return;
+  }
+  const int nCB = g.nCp / I8_BM, nPB = ctx->pairs.NPp / (32 * TN * WN);
+  constexpr int lds = i8_lds_bytes<S, WN, TN>();
+  hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nPB)), dim3(128 * WN), lds, st,
+                     g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq);
+}
+#define I8_SWITCH(ctx, ...)                                                        \
+  switch ((ctx)->i8S) {                                                            \
+    case 4: { constexpr int S_ = 4, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
+    case 5: { constexpr int S_ = 5, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
+    case 6: { constexpr int S_ = 6, WN_ = 2, TN_ = 1; __VA_ARGS__; } break;        \
+    default: { constexpr int S_ = 7, WN_ = 2, TN_ = 1; __VA_ARGS__; } break;       \
+  }
+
 void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
+  if (ctx->i8) {
+    launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 0))); });
+    launch(ctx, g, HEAVY, "assemble_i8", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 1))); });
+    return;
+  }
   launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
     if (ctx->flags & RMHMC_FLAG_FP32_METRIC) {  // precision experiment: fp32 matrix cores for the metric only
       if (ctx->big) {
@@ -565,6 +600,37 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       HIPCK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
       HIPCK(hipEventCreateWithFlags(&ctx->fj_event, hipEventDisableTiming));
     }
+    if ((flags & RMHMC_FLAG_INT8_METRIC) && !ctx->big) {
+      int S = (int)((flags >> 12) & 7u);
+      if (S == 0) S = 6;
+      if (S < 4) S = 4;
+      ctx->i8 = true;
+      ctx->i8S = S;
+      ctx->i8_bn = S <= 5 ? 128 : 64;
+      ctx->i8_nks = (int)((M + 31) / 32);
+      const int NP = D * (D + 1) / 2, NPp = (NP + ctx->i8_bn - 1) / ctx->i8_bn * ctx->i8_bn;
+      std::vector<short> pa(NPp, 0), pb(NPp, 0);
+      for (int a = 0, q = 0; a < D; ++a)
+        for (int b = a; b < D; ++b, ++q) { pa[q] = (short)a; pb[q] = (short)b; }
+      short *d_pa, *d_pb; double* d_scale;
+      RC(dalloc(ctx, &d_pa, (size_t)NPp)); RC(dalloc(ctx, &d_pb, (size_t)NPp)); RC(dalloc(ctx, &d_scale, (size_t)NPp));
+      RC(dalloc(ctx, &ctx->d_ze, (size_t)NPp));
+      HIPCK(hipMemcpyAsync(d_pa, pa.data(), NPp * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
+      HIPCK(hipMemcpyAsync(d_pb, pb.data(), NPp * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
+      RC(sync(ctx));
+      ctx->pairs = I8Pairs{d_pa, d_pb, d_scale, NP, NPp};
+      RC(dalloc(ctx, &ctx->d_Zs, (size_t)S * ctx->i8_nks * NPp * 32));
+      for (Group& g : ctx->groups) {
+        g.nCp = (g.n + I8_BM - 1) / I8_BM * I8_BM;
+        RC(dalloc(ctx, &g.Vs, (size_t)S * ctx->i8_nks * g.nCp * 32));
+        RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
+      }
+      I8_SWITCH(ctx, {
+        constexpr int lds = i8_lds_bytes<S_, WN_, TN_>();
+        auto kfn = k_assemble_i8<S_, WN_, TN_>;
+        HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      });
+    }
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     if (ctx->big) {
       RC(dalloc(ctx, &ctx->d_Wd, n * (size_t)ctx->nbk * 4096));
@@ -634,6 +700,14 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
   HIPCK(hipMemcpyAsync((void*)ctx->dd.Xr, xr.data(), xr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCK(hipMemcpyAsync((void*)ctx->dd.Xt, xt.data(), xt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCK(hipMemcpyAsync((void*)ctx->dd.t, tt.data(), tt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->i8) {  // fixed operand of the int8 metric path: slices of x_a x_b for every column pair
+    hipLaunchKernelGGL(k_zmax, dim3((unsigned)ctx->pairs.NPp), dim3(256), 0, ctx->stream, ctx->dd.Xt, (int)M, (int)Mp, ctx->pairs, ctx->d_ze,
+                       (double*)ctx->pairs.scale);
+    const dim3 grid((unsigned)((ctx->i8_nks * 8 + 255) / 256), (unsigned)ctx->pairs.NPp);
+    I8_SWITCH(ctx, hipLaunchKernelGGL((k_zsplit<S_>), grid, dim3(256), 0, ctx->stream, ctx->dd.Xt, (int)M, (int)Mp, ctx->pairs, ctx->d_ze,
+                                      ctx->i8_nks, ctx->d_Zs); (void)WN_; (void)TN_);
+    HIPCK(hipGetLastError());
+  }
   RC(sync(ctx));
   ctx->alpha = alpha;
   ctx->dd.inv_alpha = 1.0 / alpha;
