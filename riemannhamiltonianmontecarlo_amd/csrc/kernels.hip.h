@@ -1101,6 +1101,53 @@ __global__ __launch_bounds__(64) void k_hmc_end(int D, int DP, Chains ch, IterPa
 }
 
 // ---------------------------------------------------------------------------------------------
+// trace term from per-row weights: tr_d = sum_n R[c][n] x_nd (R = c_n h_n written by k_leverage_i8).  Same MFMA mapping as the
+// gradient product of k_rowpass: 16 chains per wave, row splits, partial sums to trpart (summed by k_reduce_tr).
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void k_trvec(DevData dd, int n_chains, int nsplit, const double* __restrict__ R, double* __restrict__ trpart) {
+  constexpr int DP = 16 * NB;
+  const int lane = threadIdx.x & 63;
+  const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  if (c0 >= n_chains) return;
+  const int split = blockIdx.y;
+  const int rr = lane >> 4, ci = lane & 15;
+  const int cj = min(c0 + ci, n_chains - 1);
+  const int nb16 = dd.Mp / 16;
+  const int per = (nb16 + nsplit - 1) / nsplit;
+  const int b0 = split * per, b1 = min(nb16, b0 + per);
+  const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;
+  const double* __restrict__ rp = R + (size_t)cj * dd.Mp + rr;
+  d4 T[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) T[I] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int b = b0; b < b1; ++b) {
+    const int n0 = b * 16;
+    double rv[4], xb[4][NB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rv[r] = rp[n0 + 4 * r];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + 4 * r) * DP + I];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rv[r], T[I], 0, 0, 0);
+  }
+  if (c0 + ci < n_chains) {
+    double* __restrict__ out = trpart + ((size_t)split * n_chains + c0 + ci) * DP;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = NB * (rr + 4 * r) + I;
+        if (d < dd.D) out[d] = T[I][r];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // simplified manifold MALA (widening row 8f-4; authors_code/Bayes_Log_Reg/MCMC/BLR_mMALA_Simp.m:175-290): one point
 // evaluation per transition with the RMHMC kernels, proposal and acceptance here.  Every chain does one transition
 // per step, so there is no asynchronous bookkeeping.  Hcur carries LJL + log q(w'|w) of the current transition.

@@ -329,3 +329,124 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
     Gq[(size_t)c * DP * DP + a * DP + b] = g;  // lower triangle only (contiguous in p): all the factor kernels read
   });
 }
+
+// ---------------------------------------------------------------------------------------------
+// Leverage pass on the same machinery (rmhmc.py:64-77,142-156 through the identity tr_d = sum_n c_n h_n x_nd):
+//     h_n = x_n' G^-1 x_n = sum_p Q[chain][p] Z[n][p],   Q_p = G^-1_ab (a = b) or 2 G^-1_ab (a > b)
+// is the transposed GEMM: contraction over the column pairs, one output per (chain, data row).  Q is cut per chain with the
+// chain's own exponent, Z per data row with the row's exponent (the contraction index cannot carry a scale), so the fixed
+// operand is a second sliced copy of x_a x_b:
+//     Qs[S][nkp][nCp][32]   Zt[S][nkp][NRp][32]     nkp = ceil(NP/32) stages of 32 pairs, NRp = data rows rounded up to the tile
+// The epilogue multiplies by c_n and writes R[chain][n] = c_n h_n; k_trvec contracts R with X on the fp64 matrix cores.
+// ---------------------------------------------------------------------------------------------
+// e'_n: smallest exponent with max_p |x_na x_nb| = (max_a |x_na|)^2 < 2^e'_n; zscale[n] = 2^e'_n
+__global__ __launch_bounds__(256) void k_zrowmax(const double* __restrict__ Xr, int M, int D, int DP, int NRp, int* __restrict__ ze,
+                                                 double* __restrict__ zscale) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= NRp) return;
+  double m = 0.0;
+  if (n < M)
+    for (int d = 0; d < D; ++d) m = fmax(m, fabs(Xr[(size_t)n * DP + d]));
+  m *= m;
+  int e = 0;
+  if (m > 0.0 && m < 1e300) (void)frexp(m, &e);
+  ze[n] = e;
+  zscale[n] = ldexp(1.0, e);
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_ztsplit(const double* __restrict__ Xr, int M, int DP, I8Pairs pr, const int* __restrict__ ze,
+                                                 int nkp, int NRp, int8_t* __restrict__ Zt) {
+  const int n = blockIdx.x * 32 + (threadIdx.x >> 3);  // 8 threads per data row and stage, 4 pairs each
+  const int kp = blockIdx.y, k4 = threadIdx.x & 7;
+  if (n >= NRp) return;
+  int w[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) w[s] = 0;
+  if (n < M) {
+    const int sh = 8 * S - 2 - ze[n];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = 32 * kp + 4 * k4 + k;
+      const double z = p < pr.NP ? Xr[(size_t)n * DP + pr.pa[p]] * Xr[(size_t)n * DP + pr.pb[p]] : 0.0;
+      int d[S];
+      split_digits<S>((long long)rint(ldexp(z, sh)), d);
+#pragma unroll
+      for (int s = 0; s < S; ++s) w[s] |= (d[S - 1 - s] & 0xFF) << (8 * k);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) *(int*)(Zt + (((size_t)s * nkp + kp) * NRp + n) * 32 + 4 * k4) = w[s];
+}
+
+// Q slices of one chain per workgroup.  qscale[c] = 2^(e_c - 12) (so that R = sum_g acc_g 2^-8g * qscale * zscale), NaN when
+// G^-1 is not finite (failed factorisation): the trace term, the momentum and the Hamiltonian then become NaN => rejected.
+template <int S>
+__global__ __launch_bounds__(256) void k_qsplit(const double* __restrict__ Ginv, int DP, I8Pairs pr, const int* __restrict__ phase, int nkp,
+                                                int nCp, int8_t* __restrict__ Qs, double* __restrict__ qscale) {
+  __shared__ double red[256];
+  __shared__ int sh_e;
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (phase[c] != 1) return;
+  const double* __restrict__ Gi = Ginv + (size_t)c * DP * DP;
+  double m = 0.0;
+  bool bad = false;
+  for (int p = t; p < pr.NP; p += 256) {
+    const double q = Gi[pr.pa[p] * DP + pr.pb[p]];
+    bad |= !(fabs(q) < 1e300);
+    m = fmax(m, fabs(q));
+  }
+  red[t] = bad ? __builtin_inf() : m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] = fmax(red[t], red[t + s]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    int e = 0;
+    const double mx = 2.0 * red[0];  // off-diagonal entries count twice
+    const bool ok = mx < 1e300;
+    if (ok && mx > 0.0) (void)frexp(mx, &e);
+    sh_e = e;
+    qscale[c] = ok ? ldexp(1.0, e - 12) : __builtin_nan("");
+  }
+  __syncthreads();
+  const int shf = 8 * S - 2 - sh_e;
+  const bool ok = red[0] < 1e300;
+  for (int q4 = t; q4 < nkp * 8; q4 += 256) {
+    int w[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) w[s] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = 4 * q4 + k;
+      double q = 0.0;
+      if (ok && p < pr.NP) {
+        const int a = pr.pa[p], b = pr.pb[p];
+        q = Gi[a * DP + b] * (a == b ? 1.0 : 2.0);
+      }
+      int d[S];
+      split_digits<S>((long long)rint(ldexp(q, shf)), d);
+#pragma unroll
+      for (int s = 0; s < S; ++s) w[s] |= (d[S - 1 - s] & 0xFF) << (8 * k);
+    }
+    const int kp = q4 >> 3, k4 = q4 & 7;
+#pragma unroll
+    for (int s = 0; s < S; ++s) *(int*)(Qs + (((size_t)s * nkp + kp) * nCp + c) * 32 + 4 * k4) = w[s];
+  }
+}
+
+// R[c][n] = c_n (x_n' G^-1 x_n)
+template <int S, int WN, int TN>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_leverage_i8(
+    const int8_t* __restrict__ Qs, const int8_t* __restrict__ Zt, int nCp, int NRp, int nkp, int n_chains, int Mp, const int* __restrict__ phase,
+    const double* __restrict__ qscale, const double* __restrict__ zscale, const double* __restrict__ crow, double* __restrict__ R) {
+  int cb, rb;
+  if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NRp / (32 * TN * WN), cb, rb)) return;
+  gemm_i8_tile<S, WN, TN, (WN == 4)>(Qs, Zt, nCp, NRp, nkp, cb, rb, n_chains - cb * I8_BM, Mp - rb * 32 * TN * WN, [&](int c, int n, double val) {
+    if (c >= n_chains || n >= Mp) return;
+    if (phase[c] != 1) return;
+    const size_t o = (size_t)c * Mp + n;
+    R[o] = val * qscale[c] * zscale[n] * crow[o];
+  });
+}

@@ -41,6 +41,8 @@ struct Group {
   size_t ring_pos = 0;
   int prev = -1;  // stream of the group's previous launch: 0 main, 1 side, -1 none since the last fork
   int8_t* Vs = nullptr;  // int8 metric path: slices of v, [S][nks][nCp][32]
+  int8_t* Qs = nullptr;  // slices of the doubled G^-1 entries, [S][nkp][nCp][32]
+  double* qscale = nullptr;
   int* vbad = nullptr;
   int nCp = 0;
 };
@@ -74,6 +76,10 @@ struct rmhmc_ctx {
   int i8S = 0, i8_nks = 0, i8_bn = 128;
   int8_t* d_Zs = nullptr;
   int* d_ze = nullptr;
+  int8_t* d_Zt = nullptr;   // leverage pass: x_a x_b sliced per data row, [S][nkp][NRp][32]
+  int* d_zre = nullptr;
+  double* d_zscale = nullptr;
+  int i8_nkp = 0, i8_NRp = 0;
   I8Pairs pairs{};
   // sampler parameters of the stateful API
   int L = 6, K = 4;
@@ -200,6 +206,19 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nPB)), dim3(128 * WN), lds, st,
                      g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq);
 }
+// leverage pass of the int8 path: part 0 cuts G^-1 into slices, part 1 is the GEMM (R = c .* h into rv0, v is dead by then)
+template <int S, int WN, int TN>
+void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
+  if (part == 0) {
+    hipLaunchKernelGGL((k_qsplit<S>), dim3((unsigned)g.n), dim3(256), 0, st, g.ch.trj.Ginv, ctx->DP, ctx->pairs, g.ch.phase, ctx->i8_nkp, g.nCp,
+                       g.Qs, g.qscale);
+    return;
+  }
+  const int nCB = g.nCp / I8_BM, nRB = ctx->i8_NRp / (32 * TN * WN);
+  constexpr int lds = i8_lds_bytes<S, WN, TN>();
+  hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nRB)), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp,
+                     ctx->i8_NRp, ctx->i8_nkp, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale, g.ch.rv2, g.ch.rv0);
+}
 #define I8_SWITCH(ctx, ...)                                                        \
   switch ((ctx)->i8S) {                                                            \
     case 4: { constexpr int S_ = 4, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
@@ -262,6 +281,18 @@ void launch_leverage(rmhmc_ctx* ctx, Group& g) {
     launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
       hipLaunchKernelGGL(k_trace_big, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, ctx->npairs, g.ch.rv2, hpart, g.ch.gpart);
+    });
+    launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
+      hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
+    });
+    return;
+  }
+  if (ctx->i8) {  // h_n as the transposed sliced GEMM, then tr = X' (c .* h) on the fp64 matrix cores
+    launch(ctx, g, HEAVY, "qsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 0))); });
+    launch(ctx, g, HEAVY, "leverage_i8", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 1))); });
+    launch(ctx, g, HEAVY, "trvec", [&](hipStream_t st) {
+      dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
+      NB_SWITCH(ctx, hipLaunchKernelGGL((k_trvec<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.rv0, g.ch.gpart));
     });
     launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
       hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
@@ -620,15 +651,23 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       RC(sync(ctx));
       ctx->pairs = I8Pairs{d_pa, d_pb, d_scale, NP, NPp};
       RC(dalloc(ctx, &ctx->d_Zs, (size_t)S * ctx->i8_nks * NPp * 32));
+      ctx->i8_nkp = (NP + 31) / 32;
+      ctx->i8_NRp = (ctx->Mp + ctx->i8_bn - 1) / ctx->i8_bn * ctx->i8_bn;
+      RC(dalloc(ctx, &ctx->d_Zt, (size_t)S * ctx->i8_nkp * ctx->i8_NRp * 32));
+      RC(dalloc(ctx, &ctx->d_zre, (size_t)ctx->i8_NRp)); RC(dalloc(ctx, &ctx->d_zscale, (size_t)ctx->i8_NRp));
       for (Group& g : ctx->groups) {
         g.nCp = (g.n + I8_BM - 1) / I8_BM * I8_BM;
         RC(dalloc(ctx, &g.Vs, (size_t)S * ctx->i8_nks * g.nCp * 32));
         RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
+        RC(dalloc(ctx, &g.Qs, (size_t)S * ctx->i8_nkp * g.nCp * 32));
+        RC(dalloc(ctx, &g.qscale, (size_t)g.nCp));
       }
       I8_SWITCH(ctx, {
         constexpr int lds = i8_lds_bytes<S_, WN_, TN_>();
         auto kfn = k_assemble_i8<S_, WN_, TN_>;
         HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        auto kfn2 = k_leverage_i8<S_, WN_, TN_>;
+        HIPCK(hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       });
     }
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
@@ -706,6 +745,11 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
     const dim3 grid((unsigned)((ctx->i8_nks * 8 + 255) / 256), (unsigned)ctx->pairs.NPp);
     I8_SWITCH(ctx, hipLaunchKernelGGL((k_zsplit<S_>), grid, dim3(256), 0, ctx->stream, ctx->dd.Xt, (int)M, (int)Mp, ctx->pairs, ctx->d_ze,
                                       ctx->i8_nks, ctx->d_Zs); (void)WN_; (void)TN_);
+    hipLaunchKernelGGL(k_zrowmax, dim3((unsigned)((ctx->i8_NRp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dd.Xr, (int)M, (int)D, (int)DP,
+                       ctx->i8_NRp, ctx->d_zre, ctx->d_zscale);
+    const dim3 gridt((unsigned)(ctx->i8_NRp / 32), (unsigned)ctx->i8_nkp);
+    I8_SWITCH(ctx, hipLaunchKernelGGL((k_ztsplit<S_>), gridt, dim3(256), 0, ctx->stream, ctx->dd.Xr, (int)M, (int)DP, ctx->pairs, ctx->d_zre,
+                                      ctx->i8_nkp, ctx->i8_NRp, ctx->d_Zt); (void)WN_; (void)TN_);
     HIPCK(hipGetLastError());
   }
   RC(sync(ctx));

@@ -32,10 +32,14 @@ def test_metric_and_leapfrog_match_oracle(hip, oracle, M, D, n, S):
     dirs = np.where(rs.rand(n) < 0.5, -1, 1).astype(np.int32)
 
     def fn(ctx):
-        return ctx.metric(w) + ctx.leapfrog(w, p, 0.5, dirs, 1, 4)
+        return ctx.metric(w) + ctx.leapfrog(w, p, 0.5, dirs, 1, 4) + ctx.metric_terms(w, p)
 
-    Gg, hg, gg, wg, pg, h1g, sg = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(S))
-    Go, ho, go, wo, po, h1o, so = _run(oracle, M, D, n, XX, t, fn, 0)
+    Gg, hg, gg, wg, pg, h1g, sg, trg, qg = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(S))
+    Go, ho, go, wo, po, h1o, so, tro, qo = _run(oracle, M, D, n, XX, t, fn, 0)
+    # trace term tr(G^-1 dG_d): h_n = x_n' G^-1 x_n from the transposed sliced GEMM (error relative to max|G^-1| max|x_a x_b|)
+    for c in range(n):
+        assert rel_err(trg[c], tro[c]) < 1e3 * G_TOL[S], c
+        assert rel_err(qg[c], qo[c]) < 1e3 * G_TOL[S], c
     assert np.array_equal(Gg, np.swapaxes(Gg, 1, 2))
     for c in range(n):
         assert rel_err(Gg[c], Go[c]) < G_TOL[S], c
