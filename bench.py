@@ -101,8 +101,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
-    ap.add_argument("--i8-slices", type=int, default=0, help="4..7: assemble the metric on the int8 matrix cores from that many exact byte "
-                    "slices per operand (RMHMC_FLAG_INT8_METRIC, D <= 64); 0: fp64 matrix cores")
+    ap.add_argument("--i8-slices", type=int, default=-1, help="4..7: assemble the metric (and the leverages) on the int8 matrix cores from that "
+                    "many exact byte slices per operand (RMHMC_FLAG_INT8_METRIC, 8 < D <= 64); 0: fp64 matrix cores; -1 (default): 6 slices "
+                    "(error of G 2e-14, the level of fp64 summation) where the path applies and the batch fills its 128-chain tiles")
+    ap.add_argument("--no-alternates", action="store_true", help="skip the short extra runs with the other metric-assembly variants")
     ap.add_argument("--compat", type=int, default=0, help="1: reference-compatible momentum (L'z) and guards; 0: corrected (default, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ess-iters", type=int, default=0,
@@ -139,6 +141,8 @@ def main():
     M, D = XX.shape
     L, eps, K = 6, 0.5, 4  # reference defaults, rmhmc.py:13
     flags = _capi.COMPAT if args.compat else 0
+    if args.i8_slices < 0:
+        args.i8_slices = 6 if (8 < D <= 64 and n >= 1024) else 0
     gpu_flags = flags | (_capi.int8_metric_flags(args.i8_slices) if args.i8_slices else 0)
 
     lib = _capi.load_hip_library()  # raises if the extension is not built
@@ -265,6 +269,10 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
             if os.path.exists(pmc):
                 roof["traffic"] = json.load(open(pmc)).get("assemble_bytes_per_launch")
+        if roof is not None and kt["assemble_i8"][1] > 0:
+            pmc = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+            if os.path.exists(pmc):
+                roof["traffic"] = json.load(open(pmc)).get("assemble_i8_x%d_bytes_per_launch" % args.i8_slices)
         out = {
             "metric": "leapfrog-steps/sec (whole node)", "value": value, "unit": "leapfrog-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -280,8 +288,25 @@ def main():
             out["min_ess"] = ess
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(XX, t, flags, L, eps, K)
-        print(json.dumps(out))
     ctx.close()
+    if rank == 0:
+        if world == 1 and not args.no_alternates and 8 < D <= 64 and n >= 1024:
+            # the same workload with the other metric-assembly variants, 3 steps each (not the headline)
+            alts = {}
+            for name, sl in (("fp64_mfma", 0), ("int8_x5", 5), ("int8_x6", 6)):
+                if sl == args.i8_slices:
+                    continue
+                c2 = lib.context(M, D, n, flags=flags | (_capi.int8_metric_flags(sl) if sl else 0), device=dev)
+                c2.set_data(XX, t)
+                c2.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
+                c2.chains_run(1)
+                torch.cuda.synchronize(); ta = time.perf_counter()
+                c2.chains_run(3)
+                torch.cuda.synchronize(); tb = time.perf_counter()
+                c2.close()
+                alts[name] = {"value": n * 3 / (tb - ta), "ms_per_step": (tb - ta) / 3 * 1e3}
+            out["alternates"] = alts
+        print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

@@ -23,6 +23,13 @@ def int8_metric_flags(slices=6):
     if not 4 <= int(slices) <= 7:
         raise ValueError("slices must be 4..7")
     return FLAG_INT8_METRIC | (int(slices) << 12)
+
+
+def auto_metric_flags(D, n_chains, slices=None):
+    """None: 6 slices where the int8 path applies (8 < D <= 64) and the batch fills its 128-chain tiles; 0: fp64 matrix cores"""
+    if slices is None:
+        slices = 6 if (8 < D <= 64 and n_chains >= 1024) else 0
+    return int8_metric_flags(slices) if slices else 0
 FLAG_ORACLE_LITERAL = 1 << 8
 
 ST_NOT_PD, ST_NONFINITE, ST_GUARD_P, ST_GUARD_W = 1, 2, 4, 8

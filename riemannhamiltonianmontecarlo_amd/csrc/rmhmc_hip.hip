@@ -223,7 +223,7 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
   switch ((ctx)->i8S) {                                                            \
     case 4: { constexpr int S_ = 4, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
     case 5: { constexpr int S_ = 5, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
-    case 6: { constexpr int S_ = 6, WN_ = 2, TN_ = 1; __VA_ARGS__; } break;        \
+    case 6: { constexpr int S_ = 6, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
     default: { constexpr int S_ = 7, WN_ = 2, TN_ = 1; __VA_ARGS__; } break;       \
   }
 
@@ -637,7 +637,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       if (S < 4) S = 4;
       ctx->i8 = true;
       ctx->i8S = S;
-      ctx->i8_bn = S <= 5 ? 128 : 64;
+      ctx->i8_bn = S <= 6 ? 128 : 64;
       ctx->i8_nks = (int)((M + 31) / 32);
       const int NP = D * (D + 1) / 2, NPp = (NP + ctx->i8_bn - 1) / ctx->i8_bn * ctx->i8_bn;
       std::vector<short> pa(NPp, 0), pb(NPp, 0);

@@ -79,10 +79,9 @@ int main(int argc, char** argv) {
     if (S == 6) run_case<6, 2, 1>(8192, 2080, 10000, false, 3);
     return 0;
   }
-  run_case<6, 2, 1, 0>(8192, 2048, 10000, false, 5);
+  run_case<6, 4, 1, 1>(300, 300, 1000, true, 0);
+  run_case<6, 4, 1, 1>(8192, 2080, 10000, false, 5);
   run_case<6, 2, 1, 0>(8192, 2080, 10000, false, 5);
-  run_case<6, 2, 1, 0>(8192, 2112, 10000, false, 5);
-  run_case<5, 4, 1, 0>(8192, 2048, 10000, false, 5);
-  run_case<5, 4, 1, 0>(8192, 2176, 10000, false, 5);
+  run_case<5, 4, 1, 1>(8192, 2080, 10000, false, 5);
   return 0;
 }
