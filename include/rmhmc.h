@@ -60,8 +60,10 @@ typedef struct rmhmc_ctx rmhmc_ctx;
                                           signed-byte slices of v and of x_a x_b (fixed point, int32 accumulation,
                                           fp64 combination).  Slices S in bits 12..14 (RMHMC_FLAG_INT8_SLICES(S),
                                           4..7, 0 = default 6): norm-wise error of G about 4e-10 / 2e-12 / 1e-14 /
-                                          6e-16 for S = 4 / 5 / 6 / 7 (fp64 summation itself: ~1e-15).  Ignored by
-                                          the oracle, which is always fp64. */
+                                          6e-16 for S = 4 / 5 / 6 / 7 (fp64 summation itself: ~1e-15).  Taken only
+                                          where the int32 accumulators cannot overflow for any data, M * S < 2^17
+                                          (M <= 21845 at S = 6); otherwise, and for D > 64, the fp64 matrix cores
+                                          are used.  Ignored by the oracle, which is always fp64. */
 #define RMHMC_FLAG_INT8_SLICES(S) (((uint32_t)(S) & 7u) << 12)
 #define RMHMC_FLAG_ORACLE_LITERAL (1u << 8) /* oracle only: form the DxDxD
                                                InvGdG tensor and use LU

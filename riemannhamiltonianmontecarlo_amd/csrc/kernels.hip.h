@@ -659,11 +659,15 @@ __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int 
 }
 
 // new point: factor G(w), half log-determinant, explicit inverse, log joint, and u = G^-1 p
-// (rmhmc.py:137-138,158,166-171).  Lane j solves (L L') x = e_j (column j of G^-1) and keeps its
-// solution in row j of Y.
+// (rmhmc.py:137-138,158,166-171).  One DxD matrix in LDS per chain (4 chains per CU): Cholesky in place, W = L^-1 in place
+// (lane = row, column by column from the right: W[i][j] = -(sum_{m>j} W[i][m] L[m][j]) / L[j][j] reads only columns > j of W and
+// column j of L, which is overwritten afterwards), then G^-1 = W' W on the fp64 matrix cores with the operands read straight
+// from the LDS image (A[i][k] = W[m0+k][16I+i], B[k][j] = W[m0+k][16J+j]: one ds_read per 16-column tile serves both), lower
+// tiles only.  The product is exactly symmetric by construction.
+template <int NB>
 __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int nsplit) {
   __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
-  __shared__ __attribute__((aligned(16))) double Y[64 * RM_LD];
+  constexpr int DPc = 16 * NB;
   const int D = dd.D, DP = dd.DP;
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
@@ -673,39 +677,79 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int n
   const int bad = chol_lds(A, D, lane, rdiag);
   // half log det = sum log diag(L) = -sum log(1/L_jj)   (rmhmc.py:171,175)
   const double hld = -wave_sum((lane < D) ? log(rdiag) : 0.0);
-  // forward substitution L y = e_lane
-  double* yrow = Y + lane * RM_LD;
-  for (int i = 0; i < D; ++i) {
-    const double s = neg_dot_lds(A + i * RM_LD, yrow, i, (i == lane) ? 1.0 : 0.0);
-    yrow[i] = s * rdlane(rdiag, i);
-  }
-  // backward substitution L' x = y
-  for (int i = D - 1; i >= 0; --i) {
-    double s0 = yrow[i], s1 = 0.0;
-    int k = i + 1;
-    if ((k & 1) && k < D) { s0 = fma(-A[k * RM_LD + i], yrow[k], s0); ++k; }
-    for (; k + 4 <= D; k += 4) {
-      const double l0 = A[k * RM_LD + i], l1 = A[(k + 1) * RM_LD + i], l2 = A[(k + 2) * RM_LD + i], l3 = A[(k + 3) * RM_LD + i];
-      const double2 y01 = lds2(yrow + k), y23 = lds2(yrow + k + 2);
-      s0 = fma(-l0, y01.x, s0); s1 = fma(-l1, y01.y, s1);
-      s0 = fma(-l2, y23.x, s0); s1 = fma(-l3, y23.y, s1);
+  // store L (lower, zeros above)
+  double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
+  for (int i = 0; i < D; ++i)
+    if (lane < D) Lg[i * DP + lane] = (lane <= i) ? A[i * RM_LD + lane] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  // W = L^-1 in place.  Diagonal and the zero upper triangle / padding rows first, so that every lane runs the same loop.
+  {
+    double* rowp = A + lane * RM_LD;
+    if (lane < D) {
+      rowp[lane] = rdiag;
+      for (int m = lane + 1; m < DPc; ++m) rowp[m] = 0.0;
+    } else {
+      for (int m = 0; m < DPc; ++m) rowp[m] = 0.0;
     }
-    for (; k < D; ++k) s0 = fma(-A[k * RM_LD + i], yrow[k], s0);
-    yrow[i] = (s0 + s1) * rdlane(rdiag, i);
+    __builtin_amdgcn_wave_barrier();
+    for (int j = D - 2; j >= 0; --j) {
+      double s0 = 0.0, s1 = 0.0;
+      int m = j + 1;
+      if ((m & 1) && m < D) { s0 = fma(rowp[m], A[m * RM_LD + j], s0); ++m; }
+      for (; m + 4 <= D; m += 4) {
+        const double2 w01 = lds2(rowp + m), w23 = lds2(rowp + m + 2);
+        s0 = fma(w01.x, A[m * RM_LD + j], s0); s1 = fma(w01.y, A[(m + 1) * RM_LD + j], s1);
+        s0 = fma(w23.x, A[(m + 2) * RM_LD + j], s0); s1 = fma(w23.y, A[(m + 3) * RM_LD + j], s1);
+      }
+      for (; m < D; ++m) s0 = fma(rowp[m], A[m * RM_LD + j], s0);
+      const double rj = rdlane(rdiag, j);
+      __builtin_amdgcn_wave_barrier();
+      if (lane > j && lane < D) rowp[j] = -(s0 + s1) * rj;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // G^-1 = W' W, lower 16x16 tiles (I >= J); rows of W below the first row of tile J... all rows m contribute, W[m][a] = 0 for m < a
+  constexpr int NT = NB * (NB + 1) / 2;
+  d4 acc[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  {
+    const int kk = lane >> 4, ii = lane & 15;
+    for (int m0 = 0; m0 < DPc; m0 += 4) {
+      double op[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) op[I] = A[(m0 + kk) * RM_LD + 16 * I + ii];
+      int q = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+          if (m0 + 3 >= 16 * I) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[q], 0, 0, 0);  // W[m][a] = 0 for m < a
+          ++q;
+        }
+    }
   }
   __builtin_amdgcn_wave_barrier();
-  // store L (lower, zeros above) and the symmetrised inverse; Y[j][i] = (G^-1)[i][j]
-  double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
+  // tiles back into the LDS image (lower triangle of G^-1): element (16I + (lane>>4) + 4r, 16J + (lane&15)) <-> acc[r]
+  {
+    int q = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(16 * I + (lane >> 4) + 4 * r) * RM_LD + 16 * J + (lane & 15)] = acc[q][r];
+        ++q;
+      }
+  }
+  __builtin_amdgcn_wave_barrier();
   double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
   const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
   double u = 0.0;
   for (int i = 0; i < D; ++i) {
-    const double gi = 0.5 * (Y[i * RM_LD + lane] + yrow[i]);
-    if (lane < D) {
-      Lg[i * DP + lane] = (lane <= i) ? A[i * RM_LD + lane] : 0.0;
-      Gi[i * DP + lane] = gi;
-    }
-    u = fma(gi, rdlane(pl, i), u);  // u = G^-1 p
+    const double gi = (lane <= i) ? A[i * RM_LD + lane] : A[min(lane, DPc - 1) * RM_LD + i];
+    if (lane < D) Gi[i * DP + lane] = gi;
+    u = fma((lane < D) ? gi : 0.0, rdlane(pl, i), u);  // u = G^-1 p
   }
   if (lane < D) ch.uq[(size_t)c * DP + lane] = u;
   // log joint = sum of the row-split partials + Gaussian prior (rmhmc.py:166-169, tools.py:10-14)

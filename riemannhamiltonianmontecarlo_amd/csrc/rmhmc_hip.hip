@@ -339,7 +339,11 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, boo
     ph.push_back([ctx](Group& g) { BIG(ctx, g, "factor", k_inverse_big, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096); });
     ph.push_back([ctx](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, ctx->D, ctx->DP, g.ch, g.ch.p); });
   } else {
-    ph.push_back([ctx](Group& g) { SMALL(ctx, g, "factor", k_factor_full, ctx->dd, g.ch, g.nsplit); });
+    ph.push_back([ctx](Group& g) {
+      launch(ctx, g, LIGHT, "factor", [&](hipStream_t st) {
+        NB_SWITCH(ctx, hipLaunchKernelGGL((k_factor_full<NB_>), dim3((unsigned)g.n), dim3(64), 0, st, ctx->dd, g.ch, g.nsplit));
+      });
+    });
   }
   if (metric_only) return;  // simplified mMALA needs neither the quadratic nor the trace term
   ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
@@ -631,10 +635,14 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       HIPCK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
       HIPCK(hipEventCreateWithFlags(&ctx->fj_event, hipEventDisableTiming));
     }
-    if ((flags & RMHMC_FLAG_INT8_METRIC) && !ctx->big) {
-      int S = (int)((flags >> 12) & 7u);
-      if (S == 0) S = 6;
-      if (S < 4) S = 4;
+    int i8_slices = (int)((flags >> 12) & 7u);
+    if (i8_slices == 0) i8_slices = 6;
+    if (i8_slices < 4) i8_slices = 4;
+    // int32 accumulators: a weight-g set sums (g+1) M products of two bytes, |.| <= 2^14 each.  The path is taken only where
+    // that cannot overflow whatever the data (M <= 21845 at 6 slices, 26214 at 5); longer data sets stay on the fp64 cores.
+    const bool i8_safe = (double)M * i8_slices * 16384.0 < 2147483648.0;
+    if ((flags & RMHMC_FLAG_INT8_METRIC) && !ctx->big && i8_safe) {
+      const int S = i8_slices;
       ctx->i8 = true;
       ctx->i8S = S;
       ctx->i8_bn = S <= 6 ? 128 : 64;
