@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_chol_big(DevData dd, Chains ch, int nbk
     __syncthreads();
     if (w == 0) {
       double rdiag;
-      const int bad = chol_lds(A, 64, lane, rdiag);
+      const int bad = chol_lds_blk<4>(A, 64, lane, rdiag);
       // zero the strict upper triangle of the factor image (it is stored and multiplied as a full block)
       for (int j = lane + 1; j < 64; ++j) A[lane * LD_LD + j] = 0.0;
       __builtin_amdgcn_wave_barrier();

@@ -375,7 +375,11 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     if (ctx->big)
       ph.push_back([=](Group& g) { BIG(ctx, g, "factor", k_chol_big<0>, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096, eps); });
     else
-      ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_factor_solve, D, DP, g.ch, eps); });
+      ph.push_back([=](Group& g) {
+        launch(ctx, g, LIGHT, "factor", [&](hipStream_t st) {
+          NB_SWITCH(ctx, hipLaunchKernelGGL((k_factor_solve<NB_>), dim3((unsigned)g.n), dim3(64), 0, st, D, DP, g.ch, eps));
+        });
+      });
   }
   const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
   ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_pos_final, D, DP, g.ch, guards); });
