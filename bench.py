@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--i8-slices", type=int, default=-1, help="4..7: assemble the metric (and the leverages) on the int8 matrix cores from that "
-                    "many exact byte slices per operand (RMHMC_FLAG_INT8_METRIC, 8 < D <= 64); 0: fp64 matrix cores; -1 (default): 6 slices "
+                    "many exact byte slices per operand (RMHMC_FLAG_INT8_METRIC, 8 < D <= 256); 0: fp64 matrix cores; -1 (default): 6 slices "
                     "(error of G 2e-14, the level of fp64 summation) where the path applies and the batch fills its 128-chain tiles")
     ap.add_argument("--no-alternates", action="store_true", help="skip the short extra runs with the other metric-assembly variants")
     ap.add_argument("--compat", type=int, default=0, help="1: reference-compatible momentum (L'z) and guards; 0: corrected (default, see DESIGN.md)")
@@ -142,7 +142,7 @@ def main():
     L, eps, K = 6, 0.5, 4  # reference defaults, rmhmc.py:13
     flags = _capi.COMPAT if args.compat else 0
     if args.i8_slices < 0:
-        args.i8_slices = 6 if (8 < D <= 64 and n >= 1024) else 0
+        args.i8_slices = 6 if (8 < D <= 256 and n >= 1024) else 0
     gpu_flags = flags | (_capi.int8_metric_flags(args.i8_slices) if args.i8_slices else 0)
 
     lib = _capi.load_hip_library()  # raises if the extension is not built
@@ -290,7 +290,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(XX, t, flags, L, eps, K)
     ctx.close()
     if rank == 0:
-        if world == 1 and not args.no_alternates and 8 < D <= 64 and n >= 1024:
+        if world == 1 and not args.no_alternates and 8 < D <= 256 and n >= 1024:
             # the same workload with the other metric-assembly variants, 3 steps each (not the headline)
             alts = {}
             for name, sl in (("fp64_mfma", 0), ("int8_x5", 5), ("int8_x6", 6)):

@@ -56,14 +56,15 @@ typedef struct rmhmc_ctx rmhmc_ctx;
                                             assemblies X'diag(v)X run on the fp32 matrix cores (f32 operands and
                                             accumulators); everything else stays float64.  Not reference-compatible:
                                             measured errors are in DESIGN.md.  Ignored by the D <= 8 fused path.      */
-#define RMHMC_FLAG_INT8_METRIC (1u << 5) /* HIP library, D <= 64: assemble G on the int8 matrix cores from exact
-                                          signed-byte slices of v and of x_a x_b (fixed point, int32 accumulation,
-                                          fp64 combination).  Slices S in bits 12..14 (RMHMC_FLAG_INT8_SLICES(S),
-                                          4..7, 0 = default 6): norm-wise error of G about 4e-10 / 2e-12 / 1e-14 /
-                                          6e-16 for S = 4 / 5 / 6 / 7 (fp64 summation itself: ~1e-15).  Taken only
-                                          where the int32 accumulators cannot overflow for any data, M * S < 2^17
-                                          (M <= 21845 at S = 6); otherwise, and for D > 64, the fp64 matrix cores
-                                          are used.  Ignored by the oracle, which is always fp64. */
+#define RMHMC_FLAG_INT8_METRIC (1u << 5) /* HIP library: compute the two O(M D^2) passes (metric assembly, leverages)
+                                          on the int8 matrix cores from exact signed-byte slices of the operands
+                                          (fixed point, int32 accumulation, fp64 combination).  Slices S in bits
+                                          12..14 (RMHMC_FLAG_INT8_SLICES(S), 4..7, 0 = default 6): norm-wise error
+                                          of G about 1e-9 / 5e-12 / 3e-14 / 1e-14 for S = 4 / 5 / 6 / 7 (fp64
+                                          summation itself: ~1e-15).  Contractions longer than 2^17/S terms are
+                                          summed over several launches so the int32 accumulators cannot overflow
+                                          for any data.  Not used by the fused D <= 8 path; ignored by the oracle,
+                                          which is always fp64. */
 #define RMHMC_FLAG_INT8_SLICES(S) (((uint32_t)(S) & 7u) << 12)
 #define RMHMC_FLAG_ORACLE_LITERAL (1u << 8) /* oracle only: form the DxDxD
                                                InvGdG tensor and use LU

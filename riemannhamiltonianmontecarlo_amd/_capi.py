@@ -26,9 +26,9 @@ def int8_metric_flags(slices=6):
 
 
 def auto_metric_flags(D, n_chains, slices=None):
-    """None: 6 slices where the int8 path applies (8 < D <= 64) and the batch fills its 128-chain tiles; 0: fp64 matrix cores"""
+    """None: 6 slices where the int8 path applies (8 < D <= 256) and the batch fills its 128-chain tiles; 0: fp64 matrix cores"""
     if slices is None:
-        slices = 6 if (8 < D <= 64 and n_chains >= 1024) else 0
+        slices = 6 if (8 < D <= 256 and n_chains >= 1024) else 0
     return int8_metric_flags(slices) if slices else 0
 FLAG_ORACLE_LITERAL = 1 << 8
 

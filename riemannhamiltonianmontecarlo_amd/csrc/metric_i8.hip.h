@@ -67,7 +67,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int S, int WN, int TN, int PIN, class Epilogue>
-__device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
+__device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks_total, int nks,
                                              int cb, int pb, int rows_real, int cols_real, Epilogue&& epi) {
   constexpr int BM = I8_BM, BN = 32 * TN * WN, ROWS = BM + BN, NT = 128 * WN;
   constexpr int STAGE = S * ROWS * I8_ROWB;
@@ -76,7 +76,8 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const size_t strideV = (size_t)nks * nCp * 32, strideZ = (size_t)nks * NPp * 32;
+  // nks stages starting at the given pointers; nks_total = stages per slice plane (a launch may cover part of the k range)
+  const size_t strideV = (size_t)nks_total * nCp * 32, strideZ = (size_t)nks_total * NPp * 32;
   const int8_t* gsrc[NU];
   size_t gstep[NU], gslice[NU];
   int lbase[NU];  // wave-uniform LDS byte offset of the wave's 64 units
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
                                                             int nC, int NP, double* __restrict__ C) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NPp / (32 * TN * WN), cb, pb)) return;
-  gemm_i8_tile<S, WN, TN, PIN>(Vs, Zs, nCp, NPp, nks, cb, pb, nC - cb * I8_BM, NP - pb * 32 * TN * WN,
+  gemm_i8_tile<S, WN, TN, PIN>(Vs, Zs, nCp, NPp, nks, nks, cb, pb, nC - cb * I8_BM, NP - pb * 32 * TN * WN,
                           [&](int row, int col, double val) { C[(size_t)row * NPp + col] = val; });
 }
 
@@ -270,10 +271,12 @@ __global__ __launch_bounds__(256) void k_zsplit(const double* __restrict__ Xt, i
 
 // Vs[s][ks][c][k] = digit s of rint(v 2^(8S)), v in [0, 1/4].  One workgroup per 8 chains, a thread cuts 4 data rows of one
 // chain: per stage the 8 chains' bytes are 256 contiguous bytes of every slice plane.  A non-finite v (diverged chain) raises
-// vbad[c], which turns the chain's G into NaN in the epilogue exactly as it would be in floating point.
+// vbad[c], which turns the chain's G into NaN in the epilogue exactly as it would be in floating point.  Also writes the identity
+// padding of G.
 template <int S>
 __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow, int Mp, int n_chains, const int* __restrict__ phase, int nks,
-                                                int nCp, int8_t* __restrict__ Vs, int* __restrict__ vbad) {
+                                                int nCp, int8_t* __restrict__ Vs, int* __restrict__ vbad, int D, int DP, double inv_alpha,
+                                                double* __restrict__ Gq) {
   __shared__ int sbad[8];
   const int t = threadIdx.x;
   const int cl = (t >> 3) & 7, k4 = t & 7, ksl = t >> 6;
@@ -307,6 +310,18 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
   if (bad) atomicOr(&sbad[cl], 1);
   __syncthreads();
   if (t < 8 && blockIdx.x * 8 + t < n_chains && phase[blockIdx.x * 8 + t] == 1) vbad[blockIdx.x * 8 + t] = sbad[t];
+  // padding rows D..DP-1 of G (lower triangle): the GEMM writes pairs below D only, and the blocked factorisation of the large-D
+  // path runs over all DP rows and uses Gq as a workspace in between, so the identity padding is renewed with every assembly
+  if (D < DP)
+    for (int q = 0; q < 8; ++q) {
+      const int cq = blockIdx.x * 8 + q;
+      if (cq >= n_chains || phase[cq] != 1) continue;
+      double* G = Gq + (size_t)cq * DP * DP;
+      for (int e = t; e < (DP - D) * DP; e += 256) {
+        const int r = D + e / DP, cc = e % DP;
+        if (cc <= r) G[(size_t)r * DP + cc] = (cc == r) ? inv_alpha : 0.0;
+      }
+    }
 }
 
 // the assembly proper: lower triangle of G[c] = C[c][:] * scale + I/alpha, natural row-major DP x DP like k_assemble (the
@@ -314,19 +329,23 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
 // (waves per SIMD stated explicitly: with 4 waves per workgroup the compiler otherwise budgets 256 registers and shuttles
 // accumulators through AGPR copies)
 template <int S, int WN, int TN>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks,
-                                                          I8Pairs pr, int n_chains, const int* __restrict__ phase,
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
+                                                          int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
                                                           const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, pr.NPp / (32 * TN * WN), cb, pb)) return;
-  gemm_i8_tile<S, WN, TN, (WN == 4)>(Vs, Zs, nCp, pr.NPp, nks, cb, pb, n_chains - cb * I8_BM, pr.NP - pb * 32 * TN * WN, [&](int c, int p, double val) {
+  // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow
+  gemm_i8_tile<S, WN, TN, (WN == 4)>(Vs + (size_t)ks0 * nCp * 32, Zs + (size_t)ks0 * pr.NPp * 32, nCp, pr.NPp, nks_total, nk, cb, pb,
+                                     n_chains - cb * I8_BM, pr.NP - pb * 32 * TN * WN, [&](int c, int p, double val) {
     if (c >= n_chains || p >= pr.NP) return;
     if (phase[c] != 1) return;
     const int a = pr.pa[p], b = pr.pb[p];  // b <= a: pairs run along the rows of the lower triangle
+    double* gp = Gq + (size_t)c * DP * DP + a * DP + b;  // lower triangle only (contiguous in p): all the factor kernels read
     double g = val * pr.scale[p];
-    if (a == b) g += inv_alpha;
+    if (accumulate) g += *gp;
+    else if (a == b) g += inv_alpha;
     if (vbad[c]) g = __builtin_nan("");
-    Gq[(size_t)c * DP * DP + a * DP + b] = g;  // lower triangle only (contiguous in p): all the factor kernels read
+    *gp = g;
   });
 }
 
@@ -436,17 +455,22 @@ __global__ __launch_bounds__(256) void k_qsplit(const double* __restrict__ Ginv,
   }
 }
 
-// R[c][n] = c_n (x_n' G^-1 x_n)
+// R[c][n] = c_n (x_n' G^-1 x_n)   (mulc = 0: h_n alone, the large-D trace kernel multiplies by c_n itself)
 template <int S, int WN, int TN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_leverage_i8(
-    const int8_t* __restrict__ Qs, const int8_t* __restrict__ Zt, int nCp, int NRp, int nkp, int n_chains, int Mp, const int* __restrict__ phase,
-    const double* __restrict__ qscale, const double* __restrict__ zscale, const double* __restrict__ crow, double* __restrict__ R) {
+    const int8_t* __restrict__ Qs, const int8_t* __restrict__ Zt, int nCp, int NRp, int nkp_total, int kp0, int nk, int accumulate, int mulc,
+    int n_chains, int Mp, const int* __restrict__ phase, const double* __restrict__ qscale, const double* __restrict__ zscale,
+    const double* __restrict__ crow, double* __restrict__ R) {
   int cb, rb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NRp / (32 * TN * WN), cb, rb)) return;
-  gemm_i8_tile<S, WN, TN, (WN == 4)>(Qs, Zt, nCp, NRp, nkp, cb, rb, n_chains - cb * I8_BM, Mp - rb * 32 * TN * WN, [&](int c, int n, double val) {
+  gemm_i8_tile<S, WN, TN, (WN == 4)>(Qs + (size_t)kp0 * nCp * 32, Zt + (size_t)kp0 * NRp * 32, nCp, NRp, nkp_total, nk, cb, rb,
+                                     n_chains - cb * I8_BM, Mp - rb * 32 * TN * WN, [&](int c, int n, double val) {
     if (c >= n_chains || n >= Mp) return;
     if (phase[c] != 1) return;
     const size_t o = (size_t)c * Mp + n;
-    R[o] = val * qscale[c] * zscale[n] * crow[o];
+    double r = val * qscale[c] * zscale[n];
+    if (mulc) r *= crow[o];
+    if (accumulate) r += R[o];
+    R[o] = r;
   });
 }

@@ -73,7 +73,7 @@ struct rmhmc_ctx {
   size_t fused_lds = 0;
   // int8 metric path (metric_i8.hip.h)
   bool i8 = false;
-  int i8S = 0, i8_nks = 0, i8_bn = 128;
+  int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
   int8_t* d_Zs = nullptr;
   int* d_ze = nullptr;
   int8_t* d_Zt = nullptr;   // leverage pass: x_a x_b sliced per data row, [S][nkp][NRp][32]
@@ -198,13 +198,18 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
 template <int S, int WN, int TN>
 void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part) {
   if (part == 0) {
-    hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad);
+    hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad,
+                       ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq);
     return;
   }
   const int nCB = g.nCp / I8_BM, nPB = ctx->pairs.NPp / (32 * TN * WN);
   constexpr int lds = i8_lds_bytes<S, WN, TN>();
-  hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nPB)), dim3(128 * WN), lds, st,
-                     g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq);
+  // the k range in pieces whose int32 sums cannot overflow whatever the data (one piece up to M = 21845 at 6 slices)
+  for (int ks0 = 0; ks0 < ctx->i8_nks; ks0 += ctx->i8_chunk) {
+    const int nk = std::min(ctx->i8_chunk, ctx->i8_nks - ks0);
+    hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nPB)), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp,
+                       ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq);
+  }
 }
 // leverage pass of the int8 path: part 0 cuts G^-1 into slices, part 1 is the GEMM (R = c .* h into rv0, v is dead by then)
 template <int S, int WN, int TN>
@@ -216,8 +221,12 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
   }
   const int nCB = g.nCp / I8_BM, nRB = ctx->i8_NRp / (32 * TN * WN);
   constexpr int lds = i8_lds_bytes<S, WN, TN>();
-  hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nRB)), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp,
-                     ctx->i8_NRp, ctx->i8_nkp, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale, g.ch.rv2, g.ch.rv0);
+  for (int kp0 = 0; kp0 < ctx->i8_nkp; kp0 += ctx->i8_chunk) {
+    const int nk = std::min(ctx->i8_chunk, ctx->i8_nkp - kp0);
+    hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nRB)), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp,
+                       ctx->i8_NRp, ctx->i8_nkp, kp0, nk, kp0 > 0 ? 1 : 0, ctx->big ? 0 : 1, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale,
+                       g.ch.rv2, g.ch.rv0);
+  }
 }
 #define I8_SWITCH(ctx, ...)                                                        \
   switch ((ctx)->i8S) {                                                            \
@@ -270,6 +279,23 @@ void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w) {
 }
 
 void launch_leverage(rmhmc_ctx* ctx, Group& g) {
+  if (ctx->i8) {  // h_n as the transposed sliced GEMM, then tr = X' (c .* h) on the fp64 matrix cores
+    launch(ctx, g, HEAVY, "qsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 0))); });
+    launch(ctx, g, HEAVY, "leverage_i8", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 1))); });
+    launch(ctx, g, HEAVY, "trvec", [&](hipStream_t st) {
+      if (ctx->big) {  // rv0 holds h (one "pair" plane), the large-D trace kernel multiplies by c itself
+        dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
+        hipLaunchKernelGGL(k_trace_big, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, 1, g.ch.rv2, g.ch.rv0, g.ch.gpart);
+        return;
+      }
+      dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
+      NB_SWITCH(ctx, hipLaunchKernelGGL((k_trvec<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.rv0, g.ch.gpart));
+    });
+    launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
+      hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
+    });
+    return;
+  }
   if (ctx->big) {  // per block pair leverage contributions, then the trace GEMM over 16 chains per workgroup
     double* hpart = ctx->d_hpart + (size_t)g.off * ctx->Mp;  // [pair][n][Mp] of this group (single group: off = 0)
     launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
@@ -281,18 +307,6 @@ void launch_leverage(rmhmc_ctx* ctx, Group& g) {
     launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
       hipLaunchKernelGGL(k_trace_big, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, ctx->npairs, g.ch.rv2, hpart, g.ch.gpart);
-    });
-    launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
-      hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
-    });
-    return;
-  }
-  if (ctx->i8) {  // h_n as the transposed sliced GEMM, then tr = X' (c .* h) on the fp64 matrix cores
-    launch(ctx, g, HEAVY, "qsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 0))); });
-    launch(ctx, g, HEAVY, "leverage_i8", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 1))); });
-    launch(ctx, g, HEAVY, "trvec", [&](hipStream_t st) {
-      dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
-      NB_SWITCH(ctx, hipLaunchKernelGGL((k_trvec<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.rv0, g.ch.gpart));
     });
     launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
       hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
@@ -642,11 +656,11 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     int i8_slices = (int)((flags >> 12) & 7u);
     if (i8_slices == 0) i8_slices = 6;
     if (i8_slices < 4) i8_slices = 4;
-    // int32 accumulators: a weight-g set sums (g+1) M products of two bytes, |.| <= 2^14 each.  The path is taken only where
-    // that cannot overflow whatever the data (M <= 21845 at 6 slices, 26214 at 5); longer data sets stay on the fp64 cores.
-    const bool i8_safe = (double)M * i8_slices * 16384.0 < 2147483648.0;
-    if ((flags & RMHMC_FLAG_INT8_METRIC) && !ctx->big && i8_safe) {
+    // int32 accumulators: a weight-g set sums (g+1) K products of two bytes, |.| <= 2^14 each, so one launch covers at most
+    // i8_chunk stages of 32 (21845 rows at 6 slices); longer contractions are summed over several launches in fp64.
+    if (flags & RMHMC_FLAG_INT8_METRIC) {
       const int S = i8_slices;
+      ctx->i8_chunk = std::max(1, (int)(2147483647.0 / (S * 16384.0)) / 32);
       ctx->i8 = true;
       ctx->i8S = S;
       ctx->i8_bn = S <= 6 ? 128 : 64;
@@ -685,7 +699,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     if (ctx->big) {
       RC(dalloc(ctx, &ctx->d_Wd, n * (size_t)ctx->nbk * 4096));
-      RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * n * Mp));
+      if (!(flags & RMHMC_FLAG_INT8_METRIC)) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * n * Mp));
     }
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
     {  // small-problem path eligibility (RMHMC_FUSED=0 disables it)

@@ -20,7 +20,7 @@ Keyword-only extensions (defaults preserve the one-chain contract):
   device     HIP device ordinal
   int8_slices  metric assembly on the int8 matrix cores (include/rmhmc.h, RMHMC_FLAG_INT8_METRIC): 4..7 byte slices per
              operand, 0 = fp64 matrix cores, None (default) = 6 slices (G to 2e-14, the level of fp64 summation) when the
-             path applies (8 < D <= 64) and the batch fills its 128-chain tiles (n_chains >= 1024), else fp64
+             path applies (8 < D <= 256) and the batch fills its 128-chain tiles (n_chains >= 1024), else fp64
   return_info  also return a dict(accepted=..., leapfrog_steps=...)
 
 Documented deviations: row 0 of wSaved is undefined in the reference (np.empty,

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 G_TOL = {4: 1e-8, 5: 1e-10, 6: 1e-12, 7: 1e-12}     # norm-wise, measured 2e-9 / 8e-12 / 3e-14 / 1e-14
 STEP_TOL = {4: 1e-6, 5: 1e-9, 6: 1e-9, 7: 1e-9}     # theta, p, log|G| after one leapfrog step
-SHAPES = [(1000, 64, 130), (690, 15, 5), (203, 33, 7), (129, 48, 300), (532, 12, 9), (50, 5, 64), (3000, 25, 257)]
+SHAPES = [(1000, 64, 130), (690, 15, 5), (203, 33, 7), (129, 48, 300), (532, 12, 9), (50, 5, 64), (3000, 25, 257),
+          (20, 10, 3), (33, 16, 130), (64, 17, 1), (97, 64, 129)]   # one / two k-stages, single chain, tile edges
 
 
 def _run(lib, M, D, n, XX, t, fn, flags):
@@ -118,14 +119,35 @@ def test_sampler_matches_oracle(hip, oracle):
     assert rel_err(s1, s0) < 1e-7
 
 
-def test_flag_is_ignored_on_the_large_d_path(hip, oracle):
-    M, D, n = 300, 100, 4
+@pytest.mark.parametrize("M,D,n", [(300, 100, 4), (700, 256, 6), (500, 65, 130), (1200, 130, 33)])
+def test_large_d_path(hip, oracle, M, D, n):
+    """64 < D <= 256: the same sliced GEMMs feed the blocked Cholesky / inverse kernels of the large-D path."""
     XX, t = synthetic_logreg(M, D, 2)
     rs = np.random.RandomState(1)
-    w = 0.1 * rs.randn(n, D) / np.sqrt(D)
-    Gg = _run(hip, M, D, n, XX, t, lambda c: c.metric(w)[0], _capi.int8_metric_flags(5))
-    Go = _run(oracle, M, D, n, XX, t, lambda c: c.metric(w)[0], 0)
-    assert rel_err(Gg, Go) < 1e-13
+    w = 0.1 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
+
+    def fn(ctx):
+        return ctx.metric(w) + ctx.metric_terms(w, p) + ctx.leapfrog(w, p, 0.3, 1, 1, 4)
+
+    Gg, hg, gg, trg, qg, wg, pg, h1g, sg = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(6))
+    Go, ho, go, tro, qo, wo, po, h1o, so = _run(oracle, M, D, n, XX, t, fn, 0)
+    for c in range(n):
+        assert rel_err(Gg[c], Go[c]) < 1e-12, c
+        assert rel_err(trg[c], tro[c]) < 1e-9, c
+        assert rel_err(wg[c], wo[c]) < 1e-9 and rel_err(pg[c], po[c]) < 1e-9, c
+    assert np.abs(hg - ho).max() < 1e-9
+
+
+def test_long_contraction_is_split(hip, oracle):
+    """M above the single-launch bound (21845 rows at 6 slices, 18724 at 7): the k range is summed over several launches."""
+    M, D, n = 40000, 12, 130
+    XX, t = synthetic_logreg(M, D, 5)
+    rs = np.random.RandomState(4)
+    w = 0.2 * rs.randn(n, D) / np.sqrt(D)
+    Gg, hg, _ = _run(hip, M, D, n, XX, t, lambda c: c.metric(w), _capi.int8_metric_flags(7))
+    Go, ho, _ = _run(oracle, M, D, n, XX, t, lambda c: c.metric(w), 0)
+    for c in range(n):
+        assert rel_err(Gg[c], Go[c]) < 1e-12, c
 
 
 def test_full_size_config3(hip, oracle):
