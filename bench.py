@@ -170,7 +170,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kt = {k: ctx.kernel_time(k) for k in ("assemble", "assemble_i8", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small", "fused", "total")}
+    kt = {k: ctx.kernel_time(k) for k in ("assemble", "assemble_i8", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small", "fused", "medium", "total")}
     ctx.kernel_time("disable")
     w_end, iters, acc = ctx.chains_state()
     finite = bool(np.isfinite(w_end).all())

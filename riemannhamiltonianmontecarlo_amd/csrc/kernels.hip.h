@@ -720,30 +720,14 @@ __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int 
   if (fire && lane == 0) ch.status[c] |= 8;  // RMHMC_ST_GUARD_W
 }
 
-// new point: factor G(w), half log-determinant, explicit inverse, log joint, and u = G^-1 p
-// (rmhmc.py:137-138,158,166-171).  One DxD matrix in LDS per chain (4 chains per CU): Cholesky in place, W = L^-1 in place
-// (lane = row, column by column from the right: W[i][j] = -(sum_{m>j} W[i][m] L[m][j]) / L[j][j] reads only columns > j of W and
-// column j of L, which is overwritten afterwards), then G^-1 = W' W on the fp64 matrix cores with the operands read straight
-// from the LDS image (A[i][k] = W[m0+k][16I+i], B[k][j] = W[m0+k][16J+j]: one ds_read per 16-column tile serves both), lower
-// tiles only.  The product is exactly symmetric by construction.
+// Lower triangle of (L L')^-1 in place of the Cholesky factor L held in the LDS image A (one wavefront, lane = row; rdiag as
+// produced by chol_lds_blk).  W = L^-1 in place, column by column from the right: W[i][j] = -(sum_{m>j} W[i][m] L[m][j]) / L[j][j]
+// reads only columns > j of W and column j of L, which is overwritten afterwards; then G^-1 = W' W on the fp64 matrix cores with
+// the operands read straight from the LDS image (A[i][k] = W[m0+k][16I+i], B[k][j] = W[m0+k][16J+j]: one ds_read per 16-column
+// tile serves both), lower tiles only, written back into A.
 template <int NB>
-__global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int nsplit) {
-  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
+__device__ __forceinline__ void spd_inverse_lds(double* A, int D, int lane, double rdiag) {
   constexpr int DPc = 16 * NB;
-  const int D = dd.D, DP = dd.DP;
-  const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
-  if (ch.phase[c] != 1) return;
-  load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
-  double rdiag;
-  const int bad = chol_lds_blk<NB>(A, D, lane, rdiag);
-  // half log det = sum log diag(L) = -sum log(1/L_jj)   (rmhmc.py:171,175)
-  const double hld = -wave_sum((lane < D) ? log(rdiag) : 0.0);
-  // store L (lower, zeros above)
-  double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
-  for (int i = 0; i < D; ++i)
-    if (lane < D) Lg[i * DP + lane] = (lane <= i) ? A[i * RM_LD + lane] : 0.0;
-  __builtin_amdgcn_wave_barrier();
   // W = L^-1 in place.  Diagonal and the zero upper triangle / padding rows first, so that every lane runs the same loop.
   {
     double* rowp = A + lane * RM_LD;
@@ -805,6 +789,33 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int n
       }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// new point: factor G(w), half log-determinant, explicit inverse, log joint, and u = G^-1 p
+// (rmhmc.py:137-138,158,166-171).  One DxD matrix in LDS per chain (4 chains per CU): Cholesky in place, W = L^-1 in place
+// (lane = row, column by column from the right: W[i][j] = -(sum_{m>j} W[i][m] L[m][j]) / L[j][j] reads only columns > j of W and
+// column j of L, which is overwritten afterwards), then G^-1 = W' W on the fp64 matrix cores with the operands read straight
+// from the LDS image (A[i][k] = W[m0+k][16I+i], B[k][j] = W[m0+k][16J+j]: one ds_read per 16-column tile serves both), lower
+// tiles only.  The product is exactly symmetric by construction.
+template <int NB>
+__global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int nsplit) {
+  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
+  constexpr int DPc = 16 * NB;
+  const int D = dd.D, DP = dd.DP;
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
+  if (ch.phase[c] != 1) return;
+  load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
+  double rdiag;
+  const int bad = chol_lds_blk<NB>(A, D, lane, rdiag);
+  // half log det = sum log diag(L) = -sum log(1/L_jj)   (rmhmc.py:171,175)
+  const double hld = -wave_sum((lane < D) ? log(rdiag) : 0.0);
+  // store L (lower, zeros above)
+  double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
+  for (int i = 0; i < D; ++i)
+    if (lane < D) Lg[i * DP + lane] = (lane <= i) ? A[i * RM_LD + lane] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  spd_inverse_lds<NB>(A, D, lane, rdiag);
   double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
   const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
   double u = 0.0;

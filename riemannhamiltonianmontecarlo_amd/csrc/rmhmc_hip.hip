@@ -10,6 +10,7 @@
 #include "fused_small.hip.h"
 #include "large_d.hip.h"
 #include "metric_i8.hip.h"
+#include "medium_step.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -71,6 +72,8 @@ struct rmhmc_ctx {
   bool want_G = false;
   bool fused = false;        // small-problem path: D <= 8 and X fits in LDS (fused_small.hip.h)
   size_t fused_lds = 0;
+  bool medium = false;       // one-launch leapfrog step for small batches with 8 < D <= 32 (medium_step.hip.h)
+  size_t medium_lds = 0;
   // int8 metric path (metric_i8.hip.h)
   bool i8 = false;
   int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
@@ -369,6 +372,16 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, boo
 void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   const int D = ctx->D, DP = ctx->DP, K = ctx->K;
   const double eps = ctx->eps;
+  if (ctx->medium) {  // the whole step in one launch, one workgroup per chain
+    const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
+    ph.push_back([=](Group& g) {
+      launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
+        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0);
+        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0);
+      });
+    });
+    return;
+  }
   // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
   for (int it = 0; it < K; ++it) {
     ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, it == 0 ? g.ch.p : g.ch.PM); });
@@ -528,7 +541,7 @@ int sync(rmhmc_ctx* ctx) {
 
 // upload w into trj.w, zero (or upload) p, mark every chain active, evaluate the record.
 // Leaves the streams forked: callers join before downloading.
-int eval_at(rmhmc_ctx* ctx, const double* w, const double* p) {
+int eval_at(rmhmc_ctx* ctx, const double* w, const double* p, bool sampler_init = false) {
   Chains& ch = ctx->ch;
   RC(upload_vec(ctx, ch.trj.w, w));
   if (p) RC(upload_vec(ctx, ch.p, p));
@@ -536,6 +549,14 @@ int eval_at(rmhmc_ctx* ctx, const double* w, const double* p) {
   fill_int(ctx, ch.phase, 1, ctx->n);
   fill_int(ctx, ch.status, 0, ctx->n);
   fork_streams(ctx);
+  if (sampler_init && ctx->medium) {  // same arithmetic as inside the one-launch steps (bit-exact checkpoint / resume)
+    for (Group& g : ctx->groups)
+      launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
+        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1);
+        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1);
+      });
+    return RMHMC_OK;
+  }
   launch_eval_point(ctx);
   return RMHMC_OK;
 }
@@ -702,6 +723,19 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       if (!(flags & RMHMC_FLAG_INT8_METRIC)) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * n * Mp));
     }
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
+    {  // mid-size problems in small batches: one launch per leapfrog step (RMHMC_MEDIUM=0 disables it)
+      // measured per global step at one chain (tools/bench_single.py): australian (D = 15) 108 us vs 218 us generic, heart (D = 14)
+      // 85 vs 154, german (D = 25) 236 vs 386
+      bool on = !ctx->big && D > FS_D && D <= 32 && ctx->Mp <= MS_MAXMP && n_chains <= 512;
+      if (const char* e = getenv("RMHMC_MEDIUM")) on = on && atoi(e) != 0;
+      if (on) {
+        const size_t lds = sizeof(double) * (ctx->NB == 1 ? ms_lds_doubles<1>(ctx->Mp) : ms_lds_doubles<2>(ctx->Mp));
+        if (ctx->NB == 1) HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->medium = true;
+        ctx->medium_lds = lds;
+      }
+    }
     {  // small-problem path eligibility (RMHMC_FUSED=0 disables it)
       const size_t lds = ((size_t)(FS_D + 1 + FS_WAVES) * ctx->Mp + (size_t)FS_WAVES * FS_PT) * sizeof(double);
       bool on = (D <= FS_D) && lds <= 160 * 1024;
@@ -889,7 +923,7 @@ static int init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] or NU
       });
     }
   } else {
-    RC(eval_at(ctx, theta0_host, nullptr));
+    RC(eval_at(ctx, theta0_host, nullptr, true));
     for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_commit_all, ctx->D, ctx->DP, g.ch);
   }
   join_streams(ctx);

@@ -478,3 +478,34 @@ def test_checkpoint_resume(hip):
     from test_oracle_golden import _checkpoint_resume_check
     _checkpoint_resume_check(hip, M=150, D=6, n=4)      # fused small-problem kernel
     _checkpoint_resume_check(hip, M=150, D=12, n=3)     # generic kernels
+
+
+@pytest.mark.parametrize("M,D,n", [(690, 15, 5), (1000, 25, 3), (270, 14, 70), (50, 9, 2), (2048, 32, 4)])
+def test_medium_one_launch_step_matches_generic_and_oracle(hip, oracle, monkeypatch, M, D, n):
+    """8 < D <= 32 in small batches: the whole leapfrog step runs in one launch per chain (csrc/medium_step.hip.h).  Same inputs
+    through that path, through the generic kernels (RMHMC_MEDIUM=0) and through the oracle."""
+    XX, t = synthetic_logreg(M, D, 11)
+    rs = np.random.RandomState(M + D)
+    w = 0.2 * rs.randn(n, D) / np.sqrt(D); z = rs.randn(n, D)
+    ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
+
+    def run(lib, flags):
+        with lib.context(M, D, n, flags=flags) as ctx:
+            ctx.set_data(XX, t)
+            r = ctx.transition(w, z, ul, gd, ua, L=5, eps=0.4, K=4)
+            s = ctx.sample(12, 4, 3, 0.4, 4, seed=5)
+        return r, s
+
+    for flags in (0, _capi.COMPAT):
+        rm, sm = run(hip, flags)
+        monkeypatch.setenv("RMHMC_MEDIUM", "0")
+        rg, sg = run(hip, flags)
+        monkeypatch.delenv("RMHMC_MEDIUM")
+        ro, so = run(oracle, flags)
+        for other_r, other_s in ((rg, sg), (ro, so)):
+            assert np.array_equal(rm["nsteps"], other_r["nsteps"]) and np.array_equal(rm["accepted"], other_r["accepted"])
+            assert np.array_equal(rm["status"] != 0, other_r["status"] != 0)
+            for k in ("w_prop", "p_prop", "w"):
+                assert rel_err(rm[k], other_r[k]) < TOL_TRAJ, k
+            assert rel_err(rm["H_prop"], other_r["H_prop"]) < 1e-8 and rel_err(rm["hld_prop"], other_r["hld_prop"]) < TOL_TRAJ
+            assert np.array_equal(sm[1], other_s[1]) and rel_err(sm[0], other_s[0]) < 1e-7
