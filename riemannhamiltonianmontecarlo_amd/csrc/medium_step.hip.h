@@ -310,3 +310,109 @@ __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, doub
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Plain HMC (code/hmc.py:48-62), the sampler the reference's main.py actually calls: a whole TRAJECTORY in one launch for
+// small batches (D <= 32).  The generic path spends five launches per leapfrog step and the reference draws up to 100 steps
+// per transition; here one 256-thread workgroup owns a chain, keeps w / p / gradient in LDS and does every remaining step of
+// the trajectory: momentum half step, position step, gradient and log joint at the new position (thread = data row, partial
+// sums through the wave all-reduce and one LDS hop), second half step.  A NaN momentum ends the trajectory as in k_hmc_pre.
+// eval_only: gradient and log joint at trj.w, then trj -> cur (the sampler's initial record, same arithmetic as inside a
+// trajectory).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void k_hmc_traj(DevData dd, Chains ch, double eps, int eval_only) {
+  constexpr int DPc = 16 * NB;
+  __shared__ double wv[32], pv[32], gv[32], tmp[32], red[4 * 40];
+  __shared__ int flag;
+  const int c = blockIdx.x;
+  if (ch.phase[c] != 1) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int D = dd.D, M = dd.M, Mp = dd.Mp;
+  const size_t ov = (size_t)c * DPc;
+  if (t < 32) {
+    const bool in = t < D;
+    wv[t] = in ? ch.trj.w[ov + t] : 0.0;
+    pv[t] = in ? ch.p[ov + t] : 0.0;
+    gv[t] = in ? ch.trj.grad[ov + t] : 0.0;
+  }
+  int steps = eval_only ? 1 : ch.steps_left[c];
+  int status = 0, done = 0;
+  double ljl = 0.0;
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    if (!eval_only) {  // first half step and the position step (hmc.py:52-58)
+      if (wave == 0) {
+        double p = 0.0;
+        int isnan_ = 0;
+        if (lane < D) { p = pv[lane] + eps * 0.5 * gv[lane]; isnan_ = (p != p); }
+        const unsigned long long nan = __ballot(isnan_);
+        if (lane < D) {
+          pv[lane] = p;
+          if (!nan) wv[lane] += eps * p;
+        }
+        if (lane == 0) flag = nan ? 1 : 0;
+      }
+      __syncthreads();
+      if (flag) status |= 2;
+    }
+    // gradient X'(t - e^f/(1+e^f)) and log joint sum f t - log(1+e^f) at w (hmc.py:60-61, naive forms kept: they overflow
+    // exactly where the reference does)
+    double acc[DPc];
+#pragma unroll
+    for (int d = 0; d < DPc; ++d) acc[d] = 0.0;
+    double lj = 0.0;
+    for (int n = t; n < Mp; n += 256) {
+      const double* xr = dd.Xr + (size_t)n * DPc;
+      double x[DPc];
+#pragma unroll
+      for (int d = 0; d < DPc; d += 2) { const double2 q = *(const double2*)(xr + d); x[d] = q.x; x[d + 1] = q.y; }
+      double f = 0.0;
+#pragma unroll
+      for (int d = 0; d < DPc; ++d) f = fma(x[d], wv[d], f);
+      const double ef = exp(f);
+      const double tn = dd.t[n];
+      if (n < M) lj += f * tn - log(1.0 + ef);
+      const double rn = tn - ef / (1.0 + ef);
+#pragma unroll
+      for (int d = 0; d < DPc; ++d) acc[d] = fma(rn, x[d], acc[d]);
+    }
+    fs_allreduce<DPc>(acc, lane);
+    lj = wave_sum(lj);
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < DPc; ++d) red[wave * 40 + d] = acc[d];
+      red[wave * 40 + DPc] = lj;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double part = 0.0;
+      if (lane < D) {
+        const double g = (red[lane] + red[40 + lane]) + (red[80 + lane] + red[120 + lane]) - wv[lane] * dd.inv_alpha;
+        gv[lane] = g;
+        part = dd.log_prior_const - wv[lane] * wv[lane] * 0.5 * dd.inv_alpha;
+        if (!eval_only && !(status & 2)) pv[lane] += eps * 0.5 * g;  // second half step (hmc.py:62)
+      }
+      ljl = wave_sum(part) + ((red[DPc] + red[40 + DPc]) + (red[80 + DPc] + red[120 + DPc]));
+    }
+    ++done;
+    __syncthreads();
+    if (status & 2) break;  // a NaN momentum ends the trajectory (hmc.py:56-57)
+  }
+  if (t < D) {
+    ch.trj.w[ov + t] = wv[t];
+    ch.trj.grad[ov + t] = gv[t];
+    if (!eval_only) ch.p[ov + t] = pv[t];
+    if (eval_only) { ch.cur.w[ov + t] = wv[t]; ch.cur.grad[ov + t] = gv[t]; }
+  }
+  if (t == 0) {
+    ch.trj.ljl[c] = ljl;
+    if (eval_only) {
+      ch.cur.ljl[c] = ljl;
+    } else {
+      if (status) ch.status[c] |= status;
+      ch.steps_left[c] = 0;
+      ch.steps_done[c] += done;
+    }
+  }
+}

@@ -74,6 +74,7 @@ struct rmhmc_ctx {
   size_t fused_lds = 0;
   bool medium = false;       // one-launch leapfrog step for small batches with 8 < D <= 32 (medium_step.hip.h)
   size_t medium_lds = 0;
+  bool hmc_traj = false;     // plain HMC in small batches: one launch per trajectory (k_hmc_traj)
   // int8 metric path (metric_i8.hip.h)
   bool i8 = false;
   int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
@@ -457,10 +458,23 @@ void launch_iter_end(rmhmc_ctx* ctx, const IterBase& b) {
 }
 
 // plain HMC (hmc.py:38-84): begin / half step + position / gradient pass / half step / end
+void launch_hmc_traj(rmhmc_ctx* ctx, Group& g, int eval_only) {
+  launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
+    if (ctx->NB == 1) hipLaunchKernelGGL((k_hmc_traj<1>), dim3((unsigned)g.n), dim3(256), 0, st, ctx->dd, g.ch, ctx->eps, eval_only);
+    else hipLaunchKernelGGL((k_hmc_traj<2>), dim3((unsigned)g.n), dim3(256), 0, st, ctx->dd, g.ch, ctx->eps, eval_only);
+  });
+}
+
 void launch_hmc_global_step(rmhmc_ctx* ctx, const IterBase& b) {
   std::vector<Phase> ph;
   const double eps = ctx->eps;
   ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_hmc_begin, ctx->D, ctx->DP, g.ch, ip); });
+  if (ctx->hmc_traj) {  // the whole trajectory of every chain in one launch
+    ph.push_back([ctx](Group& g) { launch_hmc_traj(ctx, g, 0); });
+    ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_hmc_end, ctx->D, ctx->DP, g.ch, ip); });
+    run_phases(ctx, ph);
+    return;
+  }
   ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_hmc_pre, ctx->D, ctx->DP, g.ch, eps); });
   ph.push_back([ctx](Group& g) { launch_rowpass<RP_G>(ctx, g, g.ch.trj.w, nullptr); });
   ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_hmc_post, ctx->dd, g.ch, eps, g.nsplit); });
@@ -735,6 +749,11 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         ctx->medium = true;
         ctx->medium_lds = lds;
       }
+    }
+    {  // plain HMC in small batches: one launch per trajectory (RMHMC_MEDIUM=0 disables it too)
+      bool on = !ctx->big && D <= 32 && n_chains <= 512;
+      if (const char* e = getenv("RMHMC_MEDIUM")) on = on && atoi(e) != 0;
+      ctx->hmc_traj = on;
     }
     {  // small-problem path eligibility (RMHMC_FUSED=0 disables it)
       const size_t lds = ((size_t)(FS_D + 1 + FS_WAVES) * ctx->Mp + (size_t)FS_WAVES * FS_PT) * sizeof(double);
@@ -1164,8 +1183,12 @@ static int hmc_init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] o
   RC(upload_vec(ctx, ctx->ch.trj.w, theta0_host));
   fill_int(ctx, ctx->ch.phase, 1, ctx->n);
   fork_streams(ctx);
-  for (Group& g : ctx->groups) launch_rowpass<RP_G>(ctx, g, g.ch.trj.w, nullptr);
-  for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_hmc_init, ctx->dd, g.ch, g.nsplit);
+  if (ctx->hmc_traj) {
+    for (Group& g : ctx->groups) launch_hmc_traj(ctx, g, 1);
+  } else {
+    for (Group& g : ctx->groups) launch_rowpass<RP_G>(ctx, g, g.ch.trj.w, nullptr);
+    for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_hmc_init, ctx->dd, g.ch, g.nsplit);
+  }
   join_streams(ctx);
   fill_int(ctx, ctx->ch.phase, 0, ctx->n);
   fill_int(ctx, ctx->ch.steps_left, 0, ctx->n);

@@ -509,3 +509,30 @@ def test_medium_one_launch_step_matches_generic_and_oracle(hip, oracle, monkeypa
                 assert rel_err(rm[k], other_r[k]) < TOL_TRAJ, k
             assert rel_err(rm["H_prop"], other_r["H_prop"]) < 1e-8 and rel_err(rm["hld_prop"], other_r["hld_prop"]) < TOL_TRAJ
             assert np.array_equal(sm[1], other_s[1]) and rel_err(sm[0], other_s[0]) < 1e-7
+
+
+@pytest.mark.parametrize("M,D,n", [(690, 15, 4), (1000, 25, 3), (250, 7, 9), (3000, 30, 2)])
+def test_hmc_one_launch_trajectory_matches_generic_and_oracle(hip, oracle, monkeypatch, M, D, n):
+    """Plain HMC in small batches runs a whole trajectory per launch (k_hmc_traj); same inputs through the five-launches-per-step
+    generic kernels (RMHMC_MEDIUM=0) and the oracle."""
+    XX, t = synthetic_logreg(M, D, 12)
+    rs = np.random.RandomState(M)
+    w = 0.1 * rs.randn(n, D); z = rs.randn(n, D); ul = rs.rand(n); ua = rs.rand(n)
+
+    def run(lib):
+        with lib.context(M, D, n, flags=0) as ctx:
+            ctx.set_data(XX, t)
+            r = ctx.hmc_transition(w, z, ul, ua, L=12, eps=0.02)
+            s = ctx.hmc_sample(20, 5, 10, 0.02, seed=8)
+        return r, s
+
+    rt, st = run(hip)
+    monkeypatch.setenv("RMHMC_MEDIUM", "0")
+    rg, sg = run(hip)
+    monkeypatch.delenv("RMHMC_MEDIUM")
+    ro, so = run(oracle)
+    for r2, s2 in ((rg, sg), (ro, so)):
+        assert np.array_equal(rt["nsteps"], r2["nsteps"]) and np.array_equal(rt["accepted"], r2["accepted"])
+        assert rel_err(rt["w_prop"], r2["w_prop"]) < 1e-9 and rel_err(rt["p_prop"], r2["p_prop"]) < 1e-9
+        assert rel_err(rt["H_prop"], r2["H_prop"]) < 1e-9
+        assert np.array_equal(st[1], s2[1]) and np.array_equal(st[2], s2[2]) and rel_err(st[0], s2[0]) < 1e-8
