@@ -276,7 +276,11 @@ def main():
         out = {
             "metric": "leapfrog-steps/sec (whole node)", "value": value, "unit": "leapfrog-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "dtype_detail": ("f64 throughout; the two O(M D^2) contractions (metric assembly, leverages) as exact integer GEMMs: operands cut into %d "
+                             "signed-byte slices, int8 MFMA with int32 accumulation, combined in f64 (G to ~2e-14 of the f64 oracle at 6 slices)"
+                             % args.i8_slices) if args.i8_slices else "f64 throughout (fp64 matrix cores)",
+            "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
                        "D": D, "M": M, "leapfrog_L": L, "step_size": eps, "fixed_point_K": K,
                        "compat": bool(args.compat), "metric_assembly": ("int8 x %d slices" % args.i8_slices) if args.i8_slices else "fp64", "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
