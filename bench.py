@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md (spec; 6.3e12 achievable, 5.94e12 measured by tools/mfma_probe)
 INT8_MFMA_PEAK = 5.0e15   # op/s dense int8 matrix (2x the bf16 rate, MI355X_MICROARCH.md)
+INT8_MFMA_STREAM = 2.85e15  # op/s a bare v_mfma_i32_32x32x32_i8 stream sustains on random bytes (power limited: 1.70 GHz at 80 % pipe
+                            # occupancy, profiles/r01_i8_gemm_probe.txt)
 FP64_MFMA_PEAK = 78.6e12  # flop/s dense fp64 matrix (spec); tools/mfma_probe measures 75.1e12
 
 WORKLOADS = {
@@ -235,6 +237,8 @@ def main():
             roof = {"bound": "mfma", "kernel": "k_assemble_i8 (sum_n v_n x_na x_nb as a sliced int8 GEMM, %d slices, v_mfma_i32_32x32x32_i8)" % S,
                     "achieved": ops / i_avg / 1e12, "peak": INT8_MFMA_PEAK / 1e12, "unit": "TOP/s", "frac": ops / i_avg / INT8_MFMA_PEAK,
                     "traffic": None, "avg_launch_ms": i_avg * 1e3, "launches": i_n,
+                    "measured_mfma_stream_peak": INT8_MFMA_STREAM / 1e12,
+                    "frac_of_measured_mfma_stream": ops / i_avg / INT8_MFMA_STREAM,
                     "fp64_equivalent_tflops": 2.0 * n * M * NP / i_avg / 1e12,
                     "fp64_equivalent_frac_of_fp64_mfma_peak": 2.0 * n * M * NP / i_avg / FP64_MFMA_PEAK,
                     "vsplit_avg_launch_ms": kt["vsplit"][0] / max(1, kt["vsplit"][1]) * 1e3,

@@ -66,3 +66,23 @@ def test_empty_inputs_rejected(oracle):
             ctx.set_data(np.zeros((4, 2)), np.zeros(4))
         with pytest.raises(ValueError):
             ctx.sample(5, 5)
+
+
+def test_int8_metric_flag_helpers():
+    """host logic of the int8 matrix-core option (include/rmhmc.h: RMHMC_FLAG_INT8_METRIC, slices in bits 12..14)"""
+    from riemannhamiltonianmontecarlo_amd import _capi
+    assert _capi.int8_metric_flags(6) == (1 << 5) | (6 << 12)
+    assert _capi.int8_metric_flags(4) & _capi.FLAG_INT8_METRIC
+    for bad in (3, 8, 0):
+        with pytest.raises(ValueError):
+            _capi.int8_metric_flags(bad)
+    # auto rule: 6 slices where the path applies and the batch fills its 128-chain tiles, else the fp64 matrix cores
+    assert _capi.auto_metric_flags(64, 8192) == _capi.int8_metric_flags(6)
+    assert _capi.auto_metric_flags(256, 4096) == _capi.int8_metric_flags(6)
+    assert _capi.auto_metric_flags(64, 100) == 0 and _capi.auto_metric_flags(8, 8192) == 0 and _capi.auto_metric_flags(300, 8192) == 0
+    assert _capi.auto_metric_flags(64, 100, 5) == _capi.int8_metric_flags(5) and _capi.auto_metric_flags(64, 8192, 0) == 0
+    # the flag values of the header and of the binding agree
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "rmhmc.h")).read()
+    assert re.search(r"#define RMHMC_FLAG_INT8_METRIC \(1u << 5\)", hdr)
+    assert re.search(r"#define RMHMC_FLAG_INT8_SLICES\(S\) \(\(\(uint32_t\)\(S\) & 7u\) << 12\)", hdr)
