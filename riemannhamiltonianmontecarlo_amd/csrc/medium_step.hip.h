@@ -320,9 +320,12 @@ __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, doub
 // eval_only: gradient and log joint at trj.w, then trj -> cur (the sampler's initial record, same arithmetic as inside a
 // trajectory).
 // ---------------------------------------------------------------------------------------------------------------
-template <int NB>
+// RPT > 0: every thread keeps its RPT data rows (n = t, t+256, ...; Mp <= 256 RPT) in registers for the whole trajectory;
+// RPT = 0: rows are re-read from L2 at every step.
+template <int NB, int RPT>
 __global__ __launch_bounds__(256) void k_hmc_traj(DevData dd, Chains ch, double eps, int eval_only) {
   constexpr int DPc = 16 * NB;
+  constexpr int RR = RPT > 0 ? RPT : 1;
   __shared__ double wv[32], pv[32], gv[32], tmp[32], red[4 * 40];
   __shared__ int flag;
   const int c = blockIdx.x;
@@ -339,6 +342,20 @@ __global__ __launch_bounds__(256) void k_hmc_traj(DevData dd, Chains ch, double 
   int steps = eval_only ? 1 : ch.steps_left[c];
   int status = 0, done = 0;
   double ljl = 0.0;
+  double xk[RR][DPc], tk[RR];
+  if (RPT > 0) {
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const int n = t + 256 * r;
+      const bool in = n < Mp;
+      tk[r] = in ? dd.t[n] : 0.0;
+#pragma unroll
+      for (int d = 0; d < DPc; d += 2) {
+        const double2 q = in ? *(const double2*)(dd.Xr + (size_t)n * DPc + d) : make_double2(0.0, 0.0);
+        xk[r][d] = q.x; xk[r][d + 1] = q.y;
+      }
+    }
+  }
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     if (!eval_only) {  // first half step and the position step (hmc.py:52-58)
@@ -362,20 +379,27 @@ __global__ __launch_bounds__(256) void k_hmc_traj(DevData dd, Chains ch, double 
 #pragma unroll
     for (int d = 0; d < DPc; ++d) acc[d] = 0.0;
     double lj = 0.0;
-    for (int n = t; n < Mp; n += 256) {
-      const double* xr = dd.Xr + (size_t)n * DPc;
-      double x[DPc];
-#pragma unroll
-      for (int d = 0; d < DPc; d += 2) { const double2 q = *(const double2*)(xr + d); x[d] = q.x; x[d + 1] = q.y; }
+    auto one_row = [&](const double (&x)[DPc], double tn, int n) {
       double f = 0.0;
 #pragma unroll
       for (int d = 0; d < DPc; ++d) f = fma(x[d], wv[d], f);
       const double ef = exp(f);
-      const double tn = dd.t[n];
       if (n < M) lj += f * tn - log(1.0 + ef);
       const double rn = tn - ef / (1.0 + ef);
 #pragma unroll
       for (int d = 0; d < DPc; ++d) acc[d] = fma(rn, x[d], acc[d]);
+    };
+    if (RPT > 0) {
+#pragma unroll
+      for (int r = 0; r < RR; ++r) one_row(xk[r], tk[r], t + 256 * r);
+    } else {
+      for (int n = t; n < Mp; n += 256) {
+        const double* xr = dd.Xr + (size_t)n * DPc;
+        double x[DPc];
+#pragma unroll
+        for (int d = 0; d < DPc; d += 2) { const double2 q = *(const double2*)(xr + d); x[d] = q.x; x[d + 1] = q.y; }
+        one_row(x, dd.t[n], n);
+      }
     }
     fs_allreduce<DPc>(acc, lane);
     lj = wave_sum(lj);

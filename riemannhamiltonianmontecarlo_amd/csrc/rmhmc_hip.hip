@@ -458,10 +458,22 @@ void launch_iter_end(rmhmc_ctx* ctx, const IterBase& b) {
 }
 
 // plain HMC (hmc.py:38-84): begin / half step + position / gradient pass / half step / end
+template <int NB>
+void launch_hmc_traj_nb(rmhmc_ctx* ctx, Group& g, int eval_only, hipStream_t st) {
+  const int rpt = (ctx->Mp + 255) / 256;  // data rows per thread; up to 4 of them stay in registers for the whole trajectory
+  const dim3 grid((unsigned)g.n), block(256);
+  switch (rpt <= 4 ? rpt : 0) {
+    case 1: hipLaunchKernelGGL((k_hmc_traj<NB, 1>), grid, block, 0, st, ctx->dd, g.ch, ctx->eps, eval_only); break;
+    case 2: hipLaunchKernelGGL((k_hmc_traj<NB, 2>), grid, block, 0, st, ctx->dd, g.ch, ctx->eps, eval_only); break;
+    case 3: hipLaunchKernelGGL((k_hmc_traj<NB, 3>), grid, block, 0, st, ctx->dd, g.ch, ctx->eps, eval_only); break;
+    case 4: hipLaunchKernelGGL((k_hmc_traj<NB, 4>), grid, block, 0, st, ctx->dd, g.ch, ctx->eps, eval_only); break;
+    default: hipLaunchKernelGGL((k_hmc_traj<NB, 0>), grid, block, 0, st, ctx->dd, g.ch, ctx->eps, eval_only); break;
+  }
+}
 void launch_hmc_traj(rmhmc_ctx* ctx, Group& g, int eval_only) {
   launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
-    if (ctx->NB == 1) hipLaunchKernelGGL((k_hmc_traj<1>), dim3((unsigned)g.n), dim3(256), 0, st, ctx->dd, g.ch, ctx->eps, eval_only);
-    else hipLaunchKernelGGL((k_hmc_traj<2>), dim3((unsigned)g.n), dim3(256), 0, st, ctx->dd, g.ch, ctx->eps, eval_only);
+    if (ctx->NB == 1) launch_hmc_traj_nb<1>(ctx, g, eval_only, st);
+    else launch_hmc_traj_nb<2>(ctx, g, eval_only, st);
   });
 }
 
