@@ -227,6 +227,18 @@ def main():
                     "note": "achieved = algorithmic bytes (80*M*D per chain per leapfrog step, SURVEY 8(d)) / measured launch time; "
                             "X (64 KB at config 2) is loaded into LDS once per launch, so real HBM traffic is ~0 and the kernel is "
                             "bound by fp64 VALU issue and exp/log latency, not by HBM"}
+        elif kt["medium"][1] > 0:
+            # small-batch path: one launch = one leapfrog step of every chain (one workgroup per chain)
+            m_s, m_n = kt["medium"]
+            m_avg = m_s / m_n
+            achieved = n * bytes_step / m_avg
+            roof = {"bound": "hbm", "kernel": "k_step_medium (whole leapfrog step in one launch, one 256-thread workgroup per chain)",
+                    "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                    "avg_launch_ms": m_avg * 1e3, "launches": m_n,
+                    "fp64_tflops": n * flops_step / m_avg / 1e12,
+                    "note": "achieved = algorithmic bytes (80*M*D per chain per leapfrog step, SURVEY 8(d)) / measured launch time.  With one "
+                            "chain this path is bound by the serial dependency chain of the step (about 70 us of barriers, LDS round trips "
+                            "and the wave-0 factorisations) plus two bookkeeping launches, not by any throughput limit"}
         elif kt["assemble_i8"][1] > 0:
             # int8 metric path: the assembly is a sliced integer GEMM, S(S+1)/2 byte products per fp64 product
             S = args.i8_slices
