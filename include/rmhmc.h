@@ -66,6 +66,8 @@ typedef struct rmhmc_ctx rmhmc_ctx;
                                           for any data.  Not used by the fused D <= 8 path; ignored by the oracle,
                                           which is always fp64. */
 #define RMHMC_FLAG_INT8_SLICES(S) (((uint32_t)(S) & 7u) << 12)
+#define RMHMC_FLAG_MMALA_FULL (1u << 6)  /* rmhmc_mmala_*: the full manifold MALA of BLR_mMALA.m (drift with the metric-
+                                          derivative terms) instead of the simplified one of BLR_mMALA_Simp.m */
 #define RMHMC_FLAG_ORACLE_LITERAL (1u << 8) /* oracle only: form the DxDxD
                                                InvGdG tensor and use LU
                                                inv/solve like rmhmc.py:64-77  */

@@ -1011,12 +1011,24 @@ static void mpoint_alloc(int D, mpoint_t *q) {
   q->Ginv = (double *)calloc((size_t)D * D, sizeof(double));
 }
 static void mpoint_free(mpoint_t *q) { free(q->w); free(q->grad); free(q->G); free(q->L); free(q->Ginv); }
+/* `grad` holds the vector the drift is built from: the gradient for the simplified sampler; for the full one
+ * (RMHMC_FLAG_MMALA_FULL, BLR_mMALA.m:198-214,231-233) gradient minus trace term, because
+ *   sum_d G^-1 dG_d G^-1 e_d = sum_n c_n h_n G^-1 x_n = G^-1 tr   (dG_d = sum_n c_n x_nd x_n x_n', h_n = x_n'G^-1 x_n)
+ * so that Mean = w + eps/2 G^-1 grad - eps G^-1 tr + eps/2 G^-1 tr = w + eps/2 G^-1 (grad - tr). */
 static void mpoint_eval(const rmhmc_ctx *c, mpoint_t *q, double *tmp) {  /* BLR_mMALA_Simp.m:186-199,229-243 */
-  metric(c, q->w, q->G, NULL);
+  const int full = (c->flags & RMHMC_FLAG_MMALA_FULL) != 0;
+  double *cvec = full ? (double *)malloc(sizeof(double) * c->M) : NULL;
+  metric(c, q->w, q->G, cvec);
   chol_lower(c->D, q->G, q->L);
   q->hld = half_logdet(c->D, q->L);
   chol_inverse(c->D, q->L, q->Ginv, tmp);
   gradient(c, q->w, q->grad);
+  if (full) {
+    double *tr = (double *)malloc(sizeof(double) * c->D);
+    trace_term_mf(c, cvec, q->Ginv, tr, tmp);
+    for (int d = 0; d < c->D; d++) q->grad[d] -= tr[d];
+    free(tr); free(cvec);
+  }
   q->ljl = log_joint(c, q->w);
 }
 static void mpoint_copy(int D, mpoint_t *d, const mpoint_t *s) {

@@ -16,6 +16,7 @@ FLAG_GUARDS = 1 << 1
 COMPAT = FLAG_MOMENTUM_LT | FLAG_GUARDS
 FLAG_FP32_METRIC = 1 << 4
 FLAG_INT8_METRIC = 1 << 5
+FLAG_MMALA_FULL = 1 << 6
 
 
 def int8_metric_flags(slices=6):

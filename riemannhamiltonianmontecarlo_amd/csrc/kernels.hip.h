@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_trvec(DevData dd, int n_chains, int nsp
 // per step, so there is no asynchronous bookkeeping.  Hcur carries LJL + log q(w'|w) of the current transition.
 // ---------------------------------------------------------------------------------------------
 // proposal w' = w + eps/2 G^-1 grad + sqrt(eps) G^-1 (L z)  ( = N(mean, eps G^-1), :217-219 )  ->  trj.w
-__global__ __launch_bounds__(64) void k_mmala_begin(int D, int DP, Chains ch, IterParams ip, double eps) {
+__global__ __launch_bounds__(64) void k_mmala_begin(int D, int DP, Chains ch, IterParams ip, double eps, int full) {
   __shared__ double zs[RM_DMAX];
   __shared__ double ts[RM_DMAX];
   const int c = blockIdx.x, lane = threadIdx.x;
@@ -1283,7 +1283,9 @@ __global__ __launch_bounds__(64) void k_mmala_begin(int D, int DP, Chains ch, It
   for (int d = lane; d < D; d += 64) {  // t = L z + sqrt(eps)/2 ... : ts = sqrt(eps) L z + eps/2 grad, then w' = w + Ginv ts
     double s = 0.0;
     for (int j = 0; j <= d; ++j) s = fma(Lc[(size_t)d * DP + j], zs[j], s);
-    ts[d] = sqrt(eps) * s + 0.5 * eps * ch.cur.grad[(size_t)c * DP + d];
+    // drift vector: gradient (BLR_mMALA_Simp.m) or gradient minus trace term (BLR_mMALA.m:231-233, see oracle/rmhmc_oracle.c mpoint_eval)
+    const double dv = ch.cur.grad[(size_t)c * DP + d] - (full ? ch.cur.tr[(size_t)c * DP + d] : 0.0);
+    ts[d] = sqrt(eps) * s + 0.5 * eps * dv;
     zz = fma(zs[d], zs[d], zz);
   }
   zz = wave_sum(zz);
@@ -1309,7 +1311,7 @@ __global__ __launch_bounds__(64) void k_mmala_begin(int D, int DP, Chains ch, It
   }
 }
 // acceptance (:229-262) once the record at w' has been evaluated
-__global__ __launch_bounds__(64) void k_mmala_end(int D, int DP, Chains ch, IterParams ip, double eps) {
+__global__ __launch_bounds__(64) void k_mmala_end(int D, int DP, Chains ch, IterParams ip, double eps, int full) {
   __shared__ double ds[RM_DMAX];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 1) return;
@@ -1319,7 +1321,7 @@ __global__ __launch_bounds__(64) void k_mmala_end(int D, int DP, Chains ch, Iter
   // d = w' + eps/2 G'^-1 grad' - w
   double u[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < D; ++j) {
-    const double gj = ch.trj.grad[(size_t)c * DP + j];
+    const double gj = ch.trj.grad[(size_t)c * DP + j] - (full ? ch.trj.tr[(size_t)c * DP + j] : 0.0);
 #pragma unroll
     for (int k = 0; k < RM_DCH; ++k) {
       const int d = lane + 64 * k;

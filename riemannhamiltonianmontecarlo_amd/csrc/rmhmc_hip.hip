@@ -343,7 +343,8 @@ void run_phases(rmhmc_ctx* ctx, const std::vector<Phase>& phases) {
 // Evaluate the point record at trj.w for every chain in phase 1 (rmhmc.py:134-161; with advance the
 // explicit momentum half step :163 too): v, r, c, log-joint partials -> G and gradient on the matrix cores
 // -> factor / inverse / u = G^-1 p -> quadratic term -> leverage pass (trace term) -> momentum update.
-void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, bool metric_only = false) {
+// mode 0: everything; 1: metric, factor, inverse, gradient, log joint only (simplified mMALA); 2: mode 1 + the trace term (full mMALA)
+void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, int mode = 0) {
   ph.push_back([ctx](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv2); });
   if (ctx->big) ph.push_back([ctx](Group& g) { SMALL(ctx, g, "small", k_finish_big, ctx->dd, g.ch, g.nsplit); });
   ph.push_back([ctx](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
@@ -363,7 +364,11 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, boo
       });
     });
   }
-  if (metric_only) return;  // simplified mMALA needs neither the quadratic nor the trace term
+  if (mode == 1) return;  // simplified mMALA needs neither the quadratic nor the trace term
+  if (mode == 2) {        // full mMALA: the trace term enters the drift, the quadratic term does not exist
+    ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
+    return;
+  }
   ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
   ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
   ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
@@ -1289,9 +1294,10 @@ int rmhmc_hmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L,
 static void launch_mmala_step(rmhmc_ctx* ctx, const IterBase& b) {
   std::vector<Phase> ph;
   const double eps = ctx->eps;
-  ph.push_back([ctx, b, eps](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_mmala_begin, ctx->D, ctx->DP, g.ch, ip, eps); });
-  eval_point_phases(ctx, ph, false, true);
-  ph.push_back([ctx, b, eps](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_mmala_end, ctx->D, ctx->DP, g.ch, ip, eps); });
+  const int full = (ctx->flags & RMHMC_FLAG_MMALA_FULL) ? 1 : 0;
+  ph.push_back([ctx, b, eps, full](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_mmala_begin, ctx->D, ctx->DP, g.ch, ip, eps, full); });
+  eval_point_phases(ctx, ph, false, full ? 2 : 1);
+  ph.push_back([ctx, b, eps, full](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_mmala_end, ctx->D, ctx->DP, g.ch, ip, eps, full); });
   run_phases(ctx, ph);
 }
 // record at theta0 (generic kernels; mMALA never uses the fused stepping kernel)

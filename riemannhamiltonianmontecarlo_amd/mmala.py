@@ -1,6 +1,7 @@
 """Simplified manifold MALA for the same model, the sampler the paper compares RMHMC with.
 
-The repository holds it only as MATLAB, authors_code/Bayes_Log_Reg/MCMC/BLR_mMALA_Simp.m (:175-290): w0 = 0,
+The repository holds it only as MATLAB, authors_code/Bayes_Log_Reg/MCMC/BLR_mMALA_Simp.m (:175-290; simplified=False: the
+full sampler BLR_mMALA.m, whose drift also carries the derivative of the metric): w0 = 0,
 StepSize 1, 10000 iterations of which 5000 burn-in, proposal N(w + eps/2 G^-1 grad, eps G^-1), Metropolis-
 Hastings with the reverse proposal evaluated under G(w').  The Python code/ directory has no counterpart, so
 this follows the naming and return convention of the two Python samplers:
@@ -16,7 +17,7 @@ import numpy as np
 from . import _capi
 
 
-def mMALA(XX, t, NumOfIterations=10000, BurnIn=5000, StepSize=1.0, *, n_chains=1, seed=None, theta0=None,
+def mMALA(XX, t, NumOfIterations=10000, BurnIn=5000, StepSize=1.0, *, simplified=True, n_chains=1, seed=None, theta0=None,
           alpha=100.0, device=0, chain_offset=0, verbose=True, return_info=False, _lib=None):
     """ SIMPLIFIED MANIFOLD MALA (Bayesian logistic regression, N(0, alpha I) prior) """
     XX = np.ascontiguousarray(XX, dtype=np.float64)
@@ -31,7 +32,9 @@ def mMALA(XX, t, NumOfIterations=10000, BurnIn=5000, StepSize=1.0, *, n_chains=1
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 62))
     lib = _lib if _lib is not None else _capi.load_hip_library()
-    with lib.context(N, D, n_chains, flags=0, device=device) as ctx:
+    # simplified=False: the full manifold MALA of BLR_mMALA.m (:198-233): the drift gains the metric-derivative terms, which
+    # collapse to eps/2 G^-1 (grad - trace term)
+    with lib.context(N, D, n_chains, flags=0 if simplified else _capi.FLAG_MMALA_FULL, device=device) as ctx:
         ctx.set_data(XX, t, alpha)
         samples, acc, seconds = ctx.mmala_sample(NumOfIterations, BurnIn, StepSize, seed=seed, chain_offset=chain_offset,
                                                  theta0=theta0)
