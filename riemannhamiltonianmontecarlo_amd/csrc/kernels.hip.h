@@ -102,11 +102,26 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 // ---------------------------------------------------------------------------------------------
 enum { RP_V = 0, RP_F = 1, RP_G = 2 };  // RP_G: as RP_F without the v / c row vectors (plain HMC)
 
-template <int NB, int MODE>
+// int8 metric path (metric_i8.hip.h): the row pass emits v already cut into signed-byte slices, Vs[S][nks][nCp][32], instead of the
+// fp64 row vector.  A lane holds rows rr, rr+4, rr+8, rr+12 of a 16-row block for its chain; a 4x4 byte transpose over the four
+// lanes of the chain (two butterfly shuffles) gives every lane four CONSECUTIVE rows, i.e. one dword of the slice plane.
+struct VSlice {
+  int8_t* Vs;
+  int* vbad;   // raised when a v is not in [0, 1/4] (non-finite: diverged chain); cleared by the host before the pass
+  int nks, nCp, S;
+};
+__device__ __forceinline__ unsigned transpose4x4_bytes(unsigned p, int rr) {
+  const unsigned a = (unsigned)__shfl_xor((int)p, 16, 64);
+  const unsigned t1 = (rr & 1) ? (((a >> 8) & 0x00FF00FFu) | (p & 0xFF00FF00u)) : ((p & 0x00FF00FFu) | ((a & 0x00FF00FFu) << 8));
+  const unsigned b = (unsigned)__shfl_xor((int)t1, 32, 64);
+  return (rr & 2) ? ((b >> 16) | (t1 & 0xFFFF0000u)) : ((t1 & 0x0000FFFFu) | (b << 16));
+}
+
+template <int NB, int MODE, bool I8 = false>
 __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
                                                  double* __restrict__ out2, double* __restrict__ gpart,
-                                                 double* __restrict__ ljl_part) {
+                                                 double* __restrict__ ljl_part, VSlice vs = VSlice{}) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
   const int lane = threadIdx.x & 63;
@@ -125,6 +140,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
   const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + ci;  // A: X[n0+ci][4kk+rr]
   const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;   // A of the gradient product
   double lj = 0.0;
+  int bad = 0;
   d4 Gr[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Gr[I] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -143,6 +159,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
     d4 F = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
+    double vv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + rr + 4 * r;
@@ -150,14 +167,15 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
       const double em = exp(-f);
       const double p = 1.0 / (1.0 + em);
       const double v = p * (1.0 - p);
+      vv[r] = v;
       const size_t o = (size_t)cj * dd.Mp + n;
       if (MODE == RP_V) {
-        if (live) out0[o] = v;
+        if (live && !I8) out0[o] = v;
       } else {
         const double ef = exp(f);
         const double tn = dd.t[n];
         if (MODE == RP_F && live) {
-          out0[o] = v;
+          if (!I8) out0[o] = v;
           out2[o] = v * (1.0 - 2.0 * p);
         }
         if (n < dd.M) lj += f * tn - log(1.0 + ef);
@@ -166,7 +184,47 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
         for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rn, Gr[I], 0, 0, 0);
       }
     }
+    if (I8 && MODE != RP_G) {
+      // byte k of Q[j] = digit j (least significant first) of rint(v 2^(8S)) for the lane's row rr + 4k; all lanes take part in
+      // the shuffles, only live chains and stages inside the slice planes are stored
+      unsigned Q[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) Q[j] = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double x = vv[r];
+        if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
+        // N = rint(x 2^(8S)) < 2^(8S-2) as two 32-bit words split at bit 24 (all in exact fp64 / int32 arithmetic: no 64-bit
+        // integer emulation): three balanced digits from the low word, the carry and up to four more from the high word
+        const double y = rint(ldexp(x, 8 * vs.S));
+        const double yh = floor(y * 5.9604644775390625e-08);  // 2^-24
+        int lo = (int)(y - yh * 16777216.0), hi = (int)yh;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int bt = (int)(signed char)(lo & 0xFF);
+          Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
+          lo = (lo - bt) >> 8;
+        }
+        hi += lo;  // carry out of the low word
+#pragma unroll
+        for (int j = 3; j < 7; ++j) {
+          const int bt = (int)(signed char)(hi & 0xFF);
+          Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
+          hi = (hi - bt) >> 8;
+        }
+      }
+      const int ks = n0 >> 5;
+      const bool st = live && ks < vs.nks;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (j < vs.S) {  // wave-uniform
+          const unsigned tq = transpose4x4_bytes(Q[j], rr);
+          if (st) *(unsigned*)(vs.Vs + (((size_t)(vs.S - 1 - j) * vs.nks + ks) * vs.nCp + cj) * 32 + (n0 & 31) + 4 * rr) = tq;
+        }
+      }
+    }
   }
+  if (I8 && MODE != RP_G && bad && live) atomicOr(&vs.vbad[cj], 1);
   if (MODE != RP_V) {
     lj = col4_sum(lj);
     if (live && rr == 0) ljl_part[(size_t)cj * nsplit + split] = lj;

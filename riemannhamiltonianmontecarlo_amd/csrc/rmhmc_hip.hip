@@ -193,8 +193,15 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
       return;
     }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
+    if (ctx->i8 && MODE != RP_G) {  // int8 metric path: v goes out as byte slices (no fp64 row vector, no k_vsplit)
+      (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
+      const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S};
+      NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
+                                        out2, g.ch.gpart, g.ch.ljl_part, vs));
+      return;
+    }
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                      out2, g.ch.gpart, g.ch.ljl_part));
+                                      out2, g.ch.gpart, g.ch.ljl_part, VSlice{}));
   });
 }
 
@@ -242,7 +249,8 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
 
 void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
   if (ctx->i8) {
-    launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 0))); });
+    if (ctx->big)  // (the generic row pass already wrote the slices)
+      launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 0))); });
     launch(ctx, g, HEAVY, "assemble_i8", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 1))); });
     return;
   }
