@@ -1031,14 +1031,11 @@ __device__ __forceinline__ void draw_normals(const IterParams& ip, int c, long l
       zs[d] = (d & 1) ? R * sn : R * cs;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // callers are one wavefront (a 64-thread block, or wave 0 of k_step_medium): LDS is in order per wave
 }
 
-__global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, IterParams ip) {
-  __shared__ double zs[RM_DMAX];
-  __shared__ double ps[RM_DMAX];
-  const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
+// start of a transition for chain c, executed by ONE wavefront (zs, ps: LDS scratch of D doubles each)
+__device__ __forceinline__ void iter_begin_dev(int D, int DP, const Chains& ch, const IterParams& ip, int c, int lane, double* zs, double* ps) {
   if (ch.phase[c] != 0) return;
   const long long it = ch.iter[c];
   if (it >= ip.iter_limit) return;
@@ -1100,7 +1097,7 @@ __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, Ite
       ch.p0[(size_t)c * DP + d] = p[k];
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   const double quad = half_quadform(ch.cur.Ginv + (size_t)c * DP * DP, D, DP, lane, ps);
   if (lane == 0) {
     const int ns = (int)ceil(u_len * (double)ip.L);  // rmhmc.py:89
@@ -1113,15 +1110,20 @@ __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, Ite
   }
 }
 
-__global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterParams ip) {
+__global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, IterParams ip) {
+  __shared__ double zs[RM_DMAX];
   __shared__ double ps[RM_DMAX];
-  const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
+  iter_begin_dev(D, DP, ch, ip, blockIdx.x, threadIdx.x, zs, ps);
+}
+
+// end of a transition for chain c (rmhmc.py:166-191), executed by ONE wavefront
+__device__ __forceinline__ void iter_end_dev(int D, int DP, const Chains& ch, const IterParams& ip, int c, int lane, double* ps) {
   const int ph = ch.phase[c];
   if (!(ph == 2 || (ph == 1 && ch.steps_left[c] == 0))) return;
   const long long it = ch.iter[c];
   for (int d = lane; d < D; d += 64) ps[d] = ch.p[(size_t)c * DP + d];
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   const double quad = half_quadform(ch.trj.Ginv + (size_t)c * DP * DP, D, DP, lane, ps);
   const double Hp = -ch.trj.ljl[c] + ch.trj.hld[c] + quad;  // rmhmc.py:171-172
   const double ratio = -Hp + ch.Hcur[c];                     // rmhmc.py:179
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterP
   }
   const bool accept = (ratio > 0.0) || (ratio > log(u_acc));  // rmhmc.py:181
   if (accept) copy_rec(ch.cur, ch.trj, c, D, DP, lane);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // (a lane reads back only what it wrote itself)
   if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S)
     for (int d = lane; d < D; d += 64)
       ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + d] = ch.cur.w[(size_t)c * DP + d];
@@ -1145,6 +1147,12 @@ __global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterP
     ch.phase[c] = 0;
     if (it + 1 == ip.iter_limit && ip.done_count) atomicAdd(ip.done_count, 1);
   }
+}
+
+__global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterParams ip) {
+  __shared__ double ps[RM_DMAX];
+  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
+  iter_end_dev(D, DP, ch, ip, blockIdx.x, threadIdx.x, ps);
 }
 
 // trj -> cur for every chain (used after the initial point evaluation)

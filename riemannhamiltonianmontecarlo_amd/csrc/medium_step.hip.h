@@ -7,7 +7,8 @@
 //   * metric assembly: the fp64 MFMA mapping of k_assemble with the data rows split over the four waves, partial tiles summed
 //     through LDS;
 //   * Cholesky (chol_lds_blk), solves and the inverse (spd_inverse_lds) by wave 0 on the LDS image.
-// Inputs / outputs are those of step_phases() in rmhmc_hip.hip: the trajectory record, p, tau, status, step counters.
+// Inputs / outputs are those of step_phases() in rmhmc_hip.hip: the trajectory record, p, tau, status, step counters; with `fold` the
+// launch is a whole global step (transition start, one leapfrog step, transition end), one launch instead of three.
 // eval_only: just the record at trj.w (what eval_point_phases(advance = false) does), used for the sampler's initial point so
 // that a resumed chain sees bit for bit the record the uninterrupted run computed inside a step.
 // v and c live in LDS (they are produced and consumed inside the launch).
@@ -24,14 +25,20 @@ constexpr int ms_lds_doubles(int Mp) {
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, double eps, int K, int guards, int eval_only) {
+__global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, double eps, int K, int guards, int eval_only, int fold, IterParams ip) {
   constexpr int DPc = 16 * NB;
   constexpr int NT = NB * (NB + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int c = blockIdx.x;
-  if (ch.phase[c] != 1) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int D = dd.D, M = dd.M, Mp = dd.Mp;
+  // fold: the transition bookkeeping of the global step (k_iter_begin before, k_iter_end after) runs inside this launch, by wave 0
+  if (fold) {
+    if (wave == 0) iter_begin_dev(D, DPc, ch, ip, c, lane, sm, sm + 64);
+    __syncthreads();
+  }
+  const bool active = ch.phase[c] == 1;
+  if (!fold && !active) return;
   double* A = sm;                          // 64 x RM_LD: G / L / W / G^-1 workspace of wave 0
   double* GI = A + 64 * RM_LD;             // 32 x MS_GLD: G^-1 of the point the step works at (symmetric, full)
   double* PT = GI + 32 * MS_GLD;           // 4 x DPc x DPc: per-wave partial metric
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, doub
     __syncthreads();
   };
 
+  if (active) {
   // ---- load the trajectory point --------------------------------------------------------------------------------
   if (t < 32) {
     const bool in = t < D;
@@ -308,6 +316,11 @@ __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, doub
         ch.steps_done[c] += 1;
       }
     }
+  }
+  }  // active
+  if (fold) {
+    __syncthreads();
+    if (wave == 0) iter_end_dev(D, DPc, ch, ip, c, lane, sm);
   }
 }
 

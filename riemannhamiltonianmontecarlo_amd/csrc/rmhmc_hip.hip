@@ -390,8 +390,8 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
     ph.push_back([=](Group& g) {
       launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
-        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0);
-        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0);
+        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0, 0, IterParams{});
+        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0, 0, IterParams{});
       });
     });
     return;
@@ -509,6 +509,17 @@ void launch_hmc_global_step(rmhmc_ctx* ctx, const IterBase& b) {
 
 void launch_global_step(rmhmc_ctx* ctx, const IterBase& b) {
   if (ctx->sampler == 1) { launch_hmc_global_step(ctx, b); return; }
+  if (ctx->medium) {  // transition start, one leapfrog step and transition end of every chain in ONE launch
+    const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
+    for (Group& g : ctx->groups) {
+      const IterParams ip = iter_params(ctx, g, b);
+      launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
+        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, 0, 1, ip);
+        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, 0, 1, ip);
+      });
+    }
+    return;
+  }
   std::vector<Phase> ph;
   ph.push_back([ctx, b](Group& g) { IterParams ip = iter_params(ctx, g, b); SMALL(ctx, g, "small", k_iter_begin, ctx->D, ctx->DP, g.ch, ip); });
   step_phases(ctx, ph);
@@ -591,8 +602,8 @@ int eval_at(rmhmc_ctx* ctx, const double* w, const double* p, bool sampler_init 
   if (sampler_init && ctx->medium) {  // same arithmetic as inside the one-launch steps (bit-exact checkpoint / resume)
     for (Group& g : ctx->groups)
       launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
-        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1);
-        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1);
+        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1, 0, IterParams{});
+        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1, 0, IterParams{});
       });
     return RMHMC_OK;
   }
