@@ -144,7 +144,7 @@ def main():
     L, eps, K = 6, 0.5, 4  # reference defaults, rmhmc.py:13
     flags = _capi.COMPAT if args.compat else 0
     if args.i8_slices < 0:
-        args.i8_slices = 6 if (8 < D <= 256 and n >= 1024) else 0
+        args.i8_slices = 6 if (8 < D <= 256 and n * float(M) * D * D >= 1e9) else 0
     gpu_flags = flags | (_capi.int8_metric_flags(args.i8_slices) if args.i8_slices else 0)
 
     lib = _capi.load_hip_library()  # raises if the extension is not built
@@ -310,7 +310,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(XX, t, flags, L, eps, K)
     ctx.close()
     if rank == 0:
-        if world == 1 and not args.no_alternates and 8 < D <= 256 and n >= 1024:
+        if world == 1 and not args.no_alternates and 8 < D <= 256 and n * float(M) * D * D >= 1e9:
             # the same workload with the other metric-assembly variants, 3 steps each (not the headline)
             alts = {}
             for name, sl in (("fp64_mfma", 0), ("int8_x5", 5), ("int8_x6", 6)):

@@ -26,11 +26,16 @@ def int8_metric_flags(slices=6):
     return FLAG_INT8_METRIC | (int(slices) << 12)
 
 
-def auto_metric_flags(D, n_chains, slices=None):
-    """None: 6 slices where the int8 path applies (8 < D <= 256) and the batch fills its 128-chain tiles; 0: fp64 matrix cores"""
+def auto_metric_flags(D, n_chains, slices=None, M=None):
+    """None: 6 slices where the int8 path pays: 8 < D <= 256 and enough work to fill its 128 x 128 tiles, n_chains * M * D^2 >= 1e9
+    (measured, tools/i8_threshold.py: 1.3-1.7x over the fp64 matrix cores from 128 chains x 10000 rows x D 64 and from 8192 chains of
+    the 690 x 15 australian data upwards; 0.76x at 600 chains x 1000 x 25), or n_chains >= 1024 when M is not given; 0: fp64 cores"""
     if slices is None:
-        slices = 6 if (8 < D <= 256 and n_chains >= 1024) else 0
+        big = (n_chains * float(M) * D * D >= 1e9) if M is not None else (n_chains >= 1024)
+        slices = 6 if (8 < D <= 256 and big) else 0
     return int8_metric_flags(slices) if slices else 0
+
+
 FLAG_ORACLE_LITERAL = 1 << 8
 
 ST_NOT_PD, ST_NONFINITE, ST_GUARD_P, ST_GUARD_W = 1, 2, 4, 8

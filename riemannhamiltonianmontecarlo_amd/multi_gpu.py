@@ -69,7 +69,7 @@ def sample_sharded(XX, t, n_chains, NumOfIterations=6000, BurnIn=1000, NumOfLeap
     summ = None
     if n_local > 0:
         th = None if theta0 is None else np.broadcast_to(theta0, (n_chains, D))[start:end]
-        with lib.context(N, D, n_local, flags=(_capi.COMPAT if compat else 0) | _capi.auto_metric_flags(D, n_local), device=local_rank if backend == "nccl" else 0) as ctx:
+        with lib.context(N, D, n_local, flags=(_capi.COMPAT if compat else 0) | _capi.auto_metric_flags(D, n_local, M=N), device=local_rank if backend == "nccl" else 0) as ctx:
             ctx.set_data(XX, t, alpha)
             if gather == "samples":
                 smp, acc, steps, secs = ctx.sample(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps,

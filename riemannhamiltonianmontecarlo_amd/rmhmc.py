@@ -20,7 +20,7 @@ Keyword-only extensions (defaults preserve the one-chain contract):
   device     HIP device ordinal
   int8_slices  metric assembly on the int8 matrix cores (include/rmhmc.h, RMHMC_FLAG_INT8_METRIC): 4..7 byte slices per
              operand, 0 = fp64 matrix cores, None (default) = 6 slices (G to 2e-14, the level of fp64 summation) when the
-             path applies (8 < D <= 256) and the batch fills its 128-chain tiles (n_chains >= 1024), else fp64
+             path applies (8 < D <= 256) and there is enough work for its tiles (n_chains * N * D^2 >= 1e9), else fp64
   return_info  also return a dict(accepted=..., leapfrog_steps=...)
 
 Documented deviations: row 0 of wSaved is undefined in the reference (np.empty,
@@ -51,7 +51,7 @@ def RMHMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=6, StepSi
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 62))
     lib = _lib if _lib is not None else _capi.load_hip_library()
-    flags = (_capi.COMPAT if compat else 0) | _capi.auto_metric_flags(D, n_chains, int8_slices)
+    flags = (_capi.COMPAT if compat else 0) | _capi.auto_metric_flags(D, n_chains, int8_slices, M=N)
     with lib.context(N, D, n_chains, flags=flags, device=device) as ctx:
         ctx.set_data(XX, t, alpha)
         samples, acc, steps, seconds = ctx.sample(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize,

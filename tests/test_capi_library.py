@@ -81,6 +81,10 @@ def test_int8_metric_flag_helpers():
     assert _capi.auto_metric_flags(256, 4096) == _capi.int8_metric_flags(6)
     assert _capi.auto_metric_flags(64, 100) == 0 and _capi.auto_metric_flags(8, 8192) == 0 and _capi.auto_metric_flags(300, 8192) == 0
     assert _capi.auto_metric_flags(64, 100, 5) == _capi.int8_metric_flags(5) and _capi.auto_metric_flags(64, 8192, 0) == 0
+    # with the data size known the rule is the amount of work, chains * M * D^2 >= 1e9
+    assert _capi.auto_metric_flags(64, 128, M=10000) == _capi.int8_metric_flags(6)
+    assert _capi.auto_metric_flags(15, 8192, M=690) == _capi.int8_metric_flags(6)
+    assert _capi.auto_metric_flags(25, 600, M=1000) == 0 and _capi.auto_metric_flags(15, 1, M=690) == 0
     # the flag values of the header and of the binding agree
     import os, re
     hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "rmhmc.h")).read()
