@@ -709,6 +709,11 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       long long ns = (6144 / ngroups + cgroups - 1) / cgroups;
       if (ns < 1) ns = 1;
       if (ns > nb16) ns = nb16;
+      {  // ... but no more than 64 splits: the consumers sum the partials serially (small batches: 10-20 % per step, tools/i8_threshold.py)
+        long long cap = 64;
+        if (const char* e = getenv("RMHMC_NSPLIT_MAX")) { const long long v = atoll(e); if (v >= 1) cap = v; }
+        if (ns > cap) ns = cap;
+      }
       g.nsplit = (int)ns;
       g.ch = chains_view(ctx, g.off, g.n);
       g.ch.hiprio = hiprio;

@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from riemannhamiltonianmontecarlo_amd import _capi
 from riemannhamiltonianmontecarlo_amd.data import synthetic_logreg
 lib = _capi.load_hip_library()
-for (M, D, n) in [(690, 15, 8192), (1000, 25, 8192), (2000, 33, 8192), (5000, 48, 8192), (10000, 64, 2048), (10000, 64, 1024), (10000, 32, 8192), (10000, 64, 512), (10000, 64, 256), (10000, 64, 128), (1000, 25, 600)]:
+SHAPES = [(690, 15, 8192), (1000, 25, 8192), (2000, 33, 8192), (5000, 48, 8192), (10000, 64, 2048), (10000, 64, 1024), (10000, 32, 8192), (10000, 64, 512), (10000, 64, 256), (10000, 64, 128), (1000, 25, 600)]
+if len(sys.argv) > 1:
+    SHAPES = [(10000, 64, 512), (10000, 64, 256), (10000, 64, 128), (1000, 25, 600), (10000, 64, 8192)]
+for (M, D, n) in SHAPES:
     XX, t = synthetic_logreg(M, D, 1)
     res = []
     for fl in (0, _capi.int8_metric_flags(6)):
