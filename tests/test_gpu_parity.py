@@ -257,11 +257,13 @@ def test_errors(hip):
             ctx.chains_run(1)                       # chains_init not called
 
 
-def test_two_group_pingpong_matches_oracle(hip, oracle, monkeypatch):
+@pytest.mark.parametrize("D,extra", [(40, 0), (40, _capi.int8_metric_flags(6)), (20, 0)])
+def test_two_group_pingpong_matches_oracle(hip, oracle, monkeypatch, D, extra):
     """Large batches are split into two chain groups ping-ponged over two HIP streams; force that
-    scheduling at a small size and check transitions, the sampler and the stepping API against the oracle."""
+    scheduling at a small size and check transitions, the sampler and the stepping API against the oracle
+    (D = 40: generic kernels, with the fp64 and with the int8 matrix-core passes; D = 20: the one-launch step)."""
     monkeypatch.setenv("RMHMC_GROUPS", "2")
-    M, D, n = 500, 20, 150
+    M, n = 500, 150
     rs = np.random.RandomState(21)
     w = 0.1 * rs.randn(n, D); z = rs.randn(n, D); ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
 
@@ -272,7 +274,7 @@ def test_two_group_pingpong_matches_oracle(hip, oracle, monkeypatch):
         s = ctx.sample(6, 2, L=3, seed=5, chain_offset=7)
         return r, s
 
-    (rg, sg), (ro, so) = _both(hip, oracle, M, D, n, fn)
+    (rg, sg), (ro, so) = _both(hip, oracle, M, D, n, fn, flags=_capi.COMPAT | extra)
     assert np.array_equal(rg["nsteps"], ro["nsteps"]) and np.array_equal(rg["accepted"], ro["accepted"])
     assert rel_err(rg["w_prop"], ro["w_prop"]) < TOL_TRAJ and rel_err(rg["p_prop"], ro["p_prop"]) < TOL_TRAJ
     assert rel_err(rg["w"], ro["w"]) < TOL_TRAJ
