@@ -32,6 +32,12 @@ __device__ __forceinline__ int i8_lds_off(int row, int half) { return row * I8_R
 #define I8_GC 4
 #define I8_GP 8
 __device__ __forceinline__ bool i8_tile_of_block(int b, int nCB, int nPB, int& cb, int& pb) {
+  if (nCB < 8) {  // fewer chain blocks than XCDs: the grouping below would leave whole XCDs idle, so the tiles are simply dealt round
+    if (b >= nCB * nPB) return false;
+    cb = b % nCB;
+    pb = b / nCB;
+    return true;
+  }
   const int xcd = b & 7, j = b >> 3;
   const int cbs = (nCB - xcd + 7) >> 3;  // chain blocks of this XCD
   if (j >= cbs * nPB) return false;
@@ -331,22 +337,38 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
 template <int S, int WN, int TN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
                                                           int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
-                                                          const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq) {
+                                                          const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
+                                                          size_t plane_stride) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, pr.NPp / (32 * TN * WN), cb, pb)) return;
-  // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow
-  gemm_i8_tile<S, WN, TN, (WN == 4)>(Vs + (size_t)ks0 * nCp * 32, Zs + (size_t)ks0 * pr.NPp * 32, nCp, pr.NPp, nks_total, nk, cb, pb,
+  // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow.
+  // gridDim.y > 1 (small batches, too few tiles to fill the chip): the k range is cut into gridDim.y pieces, piece y writes plane y of
+  // Gq (plane_stride apart) and k_sum_planes adds the planes up in a fixed order.
+  const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kb = ks0 + (int)blockIdx.y * per, kn = min(per, ks0 + nk - kb);
+  double* __restrict__ Gout = Gq + (size_t)blockIdx.y * plane_stride;
+  const bool first = blockIdx.y == 0;
+  gemm_i8_tile<S, WN, TN, (WN == 4)>(Vs + (size_t)kb * nCp * 32, Zs + (size_t)kb * pr.NPp * 32, nCp, pr.NPp, nks_total, kn, cb, pb,
                                      n_chains - cb * I8_BM, pr.NP - pb * 32 * TN * WN, [&](int c, int p, double val) {
     if (c >= n_chains || p >= pr.NP) return;
     if (phase[c] != 1) return;
     const int a = pr.pa[p], b = pr.pb[p];  // b <= a: pairs run along the rows of the lower triangle
-    double* gp = Gq + (size_t)c * DP * DP + a * DP + b;  // lower triangle only (contiguous in p): all the factor kernels read
+    double* gp = Gout + (size_t)c * DP * DP + a * DP + b;  // lower triangle only (contiguous in p): all the factor kernels read
     double g = val * pr.scale[p];
     if (accumulate) g += *gp;
-    else if (a == b) g += inv_alpha;
+    else if (a == b && first) g += inv_alpha;
     if (vbad[c]) g = __builtin_nan("");
     *gp = g;
   });
+}
+
+// dst[i] = sum over planes of src[plane][i], in plane order (deterministic)
+__global__ __launch_bounds__(256) void k_sum_planes(double* __restrict__ dst, const double* __restrict__ src, int planes, size_t plane_stride, size_t count) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  double s = src[i];
+  for (int q = 1; q < planes; ++q) s += src[(size_t)q * plane_stride + i];
+  dst[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -460,17 +482,20 @@ template <int S, int WN, int TN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_leverage_i8(
     const int8_t* __restrict__ Qs, const int8_t* __restrict__ Zt, int nCp, int NRp, int nkp_total, int kp0, int nk, int accumulate, int mulc,
     int n_chains, int Mp, const int* __restrict__ phase, const double* __restrict__ qscale, const double* __restrict__ zscale,
-    const double* __restrict__ crow, double* __restrict__ R) {
+    const double* __restrict__ crow, double* __restrict__ R, size_t plane_stride) {
   int cb, rb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NRp / (32 * TN * WN), cb, rb)) return;
-  gemm_i8_tile<S, WN, TN, (WN == 4)>(Qs + (size_t)kp0 * nCp * 32, Zt + (size_t)kp0 * NRp * 32, nCp, NRp, nkp_total, nk, cb, rb,
+  const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;  // k-split planes as in k_assemble_i8
+  const int kb = kp0 + (int)blockIdx.y * per, kn = min(per, kp0 + nk - kb);
+  double* __restrict__ Rout = R + (size_t)blockIdx.y * plane_stride;
+  gemm_i8_tile<S, WN, TN, (WN == 4)>(Qs + (size_t)kb * nCp * 32, Zt + (size_t)kb * NRp * 32, nCp, NRp, nkp_total, kn, cb, rb,
                                      n_chains - cb * I8_BM, Mp - rb * 32 * TN * WN, [&](int c, int n, double val) {
     if (c >= n_chains || n >= Mp) return;
     if (phase[c] != 1) return;
     const size_t o = (size_t)c * Mp + n;
     double r = val * qscale[c] * zscale[n];
     if (mulc) r *= crow[o];
-    if (accumulate) r += R[o];
-    R[o] = r;
+    if (accumulate) r += Rout[o];
+    Rout[o] = r;
   });
 }

@@ -44,6 +44,8 @@ struct Group {
   int8_t* Vs = nullptr;  // int8 metric path: slices of v, [S][nks][nCp][32]
   int8_t* Qs = nullptr;  // slices of the doubled G^-1 entries, [S][nkp][nCp][32]
   double* qscale = nullptr;
+  double *Gpart = nullptr, *Rpart = nullptr;  // k-split planes of small batches ([ksplit][n][DP*DP], [ksplit][n][Mp])
+  int ksplit_a = 1, ksplit_l = 1;
   int* vbad = nullptr;
   int nCp = 0;
 };
@@ -215,11 +217,19 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   }
   const int nCB = g.nCp / I8_BM, nPB = ctx->pairs.NPp / (32 * TN * WN);
   constexpr int lds = i8_lds_bytes<S, WN, TN>();
+  const unsigned nblk = (unsigned)(nCB < 8 ? nCB * nPB : (nCB + 7) / 8 * 8 * nPB);  // (fewer than 8 chain blocks: tiles are dealt round)
+  if (g.ksplit_a > 1) {  // small batch: too few tiles to fill the chip, so the k range is cut into planes that are summed afterwards
+    const size_t plane = (size_t)g.n * ctx->DP * ctx->DP;
+    hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_a), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks,
+                       0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane);
+    hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.Gq, g.Gpart, g.ksplit_a, plane, plane);
+    return;
+  }
   // the k range in pieces whose int32 sums cannot overflow whatever the data (one piece up to M = 21845 at 6 slices)
   for (int ks0 = 0; ks0 < ctx->i8_nks; ks0 += ctx->i8_chunk) {
     const int nk = std::min(ctx->i8_chunk, ctx->i8_nks - ks0);
-    hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nPB)), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp,
-                       ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq);
+    hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp,
+                       ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0);
   }
 }
 // leverage pass of the int8 path: part 0 cuts G^-1 into slices, part 1 is the GEMM (R = c .* h into rv0, v is dead by then)
@@ -232,11 +242,19 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
   }
   const int nCB = g.nCp / I8_BM, nRB = ctx->i8_NRp / (32 * TN * WN);
   constexpr int lds = i8_lds_bytes<S, WN, TN>();
+  const unsigned nblk = (unsigned)(nCB < 8 ? nCB * nRB : (nCB + 7) / 8 * 8 * nRB);
+  if (g.ksplit_l > 1) {
+    const size_t plane = (size_t)g.n * ctx->Mp;
+    hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_l), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp, ctx->i8_NRp,
+                       ctx->i8_nkp, 0, ctx->i8_nkp, 0, ctx->big ? 0 : 1, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale, g.ch.rv2, g.Rpart, plane);
+    hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.rv0, g.Rpart, g.ksplit_l, plane, plane);
+    return;
+  }
   for (int kp0 = 0; kp0 < ctx->i8_nkp; kp0 += ctx->i8_chunk) {
     const int nk = std::min(ctx->i8_chunk, ctx->i8_nkp - kp0);
-    hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3((unsigned)((nCB + 7) / 8 * 8 * nRB)), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp,
+    hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3(nblk), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp,
                        ctx->i8_NRp, ctx->i8_nkp, kp0, nk, kp0 > 0 ? 1 : 0, ctx->big ? 0 : 1, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale,
-                       g.ch.rv2, g.ch.rv0);
+                       g.ch.rv2, g.ch.rv0, (size_t)0);
   }
 }
 #define I8_SWITCH(ctx, ...)                                                        \
@@ -763,6 +781,19 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
         RC(dalloc(ctx, &g.Qs, (size_t)S * ctx->i8_nkp * g.nCp * 32));
         RC(dalloc(ctx, &g.qscale, (size_t)g.nCp));
+        // small batches: cut the k range so that about 256 workgroups exist (at least 8 stages per piece, at most 16 pieces; only
+        // when the whole range fits one overflow-safe launch)
+        auto pieces = [&](long long tiles, int stages) {
+          long long k = std::min<long long>(16, 256 / std::max<long long>(1, tiles));
+          k = std::min<long long>(k, stages / 8);
+          if (k < 2 || stages > ctx->i8_chunk || ctx->big) return 1;  // (large-D: the identity padding of G lives in Gq itself)
+          const int per = (int)((stages + k - 1) / k);
+          return (stages + per - 1) / per;
+        };
+        g.ksplit_a = pieces((long long)(g.nCp / I8_BM) * (NPp / ctx->i8_bn), ctx->i8_nks);
+        g.ksplit_l = pieces((long long)(g.nCp / I8_BM) * (ctx->i8_NRp / ctx->i8_bn), ctx->i8_nkp);
+        if (g.ksplit_a > 1) RC(dalloc(ctx, &g.Gpart, (size_t)g.ksplit_a * g.n * ctx->DP * ctx->DP));
+        if (g.ksplit_l > 1) RC(dalloc(ctx, &g.Rpart, (size_t)g.ksplit_l * g.n * ctx->Mp));
       }
       I8_SWITCH(ctx, {
         constexpr int lds = i8_lds_bytes<S_, WN_, TN_>();

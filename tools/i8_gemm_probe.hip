@@ -75,6 +75,12 @@ static double run_case(int nC, int NP, int K, bool check, int reps) {
 int main(int argc, char** argv) {
   if (argc > 1) {  // single timed case for counter collection
     const int S = atoi(argv[1]);
+    if (S == 1) {  // small-batch shapes: one chain block, full k range and one 21-stage piece of it
+      run_case<6, 4, 1, 1>(128, 2080, 10000, false, 10);
+      run_case<6, 4, 1, 1>(128, 2080, 672, false, 10);
+      run_case<6, 4, 1, 1>(1920, 2080, 672, false, 10);
+      return 0;
+    }
     if (S == 5) run_case<5, 4, 1>(8192, 2080, 10000, false, 3);
     if (S == 6) run_case<6, 2, 1>(8192, 2080, 10000, false, 3);
     return 0;
