@@ -727,8 +727,9 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       long long ns = (6144 / ngroups + cgroups - 1) / cgroups;
       if (ns < 1) ns = 1;
       if (ns > nb16) ns = nb16;
-      {  // ... but no more than 64 splits: the consumers sum the partials serially (small batches: 10-20 % per step, tools/i8_threshold.py)
-        long long cap = 64;
+      {  // ... but for short data sets no more than 64 splits: the consumers sum the partials serially (600 chains x 1000 rows x D 25:
+         // 0.61 -> 0.52 ms per step; long data sets in small batches need the parallelism: 128 chains x 10000 rows 5.9 -> 8.3 ms when capped)
+        long long cap = ctx->Mp <= 4096 ? 64 : nb16;
         if (const char* e = getenv("RMHMC_NSPLIT_MAX")) { const long long v = atoll(e); if (v >= 1) cap = v; }
         if (ns > cap) ns = cap;
       }
