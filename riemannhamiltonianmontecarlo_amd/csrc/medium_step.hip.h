@@ -24,9 +24,12 @@ constexpr int ms_lds_doubles(int Mp) {
   return 64 * RM_LD + 32 * MS_GLD + 4 * (16 * NB) * (16 * NB) + 2 * Mp + 12 * 32 + 4 * 40;
 }
 
-template <int NB>
+// RPT > 0: every thread keeps its RPT data rows (n = t, t + 256, ...; Mp <= 256 RPT) in registers for the whole launch, so the ~11 row
+// passes of a step read X once; RPT = 0: rows are re-read from L2 in every pass (one row ahead).
+template <int NB, int RPT>
 __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, double eps, int K, int guards, int eval_only, int fold, IterParams ip) {
   constexpr int DPc = 16 * NB;
+  constexpr int RR = RPT > 0 ? RPT : 1;
   constexpr int NT = NB * (NB + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int c = blockIdx.x;
@@ -73,26 +76,26 @@ __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, doub
   };
   // row passes.  MODE 0: v (and c) at `wp`; 1: v, c, gradient partials and log joint at `wp`; 2: q_d = sum c_n (x_n.u)^2 x_nd;
   // 3: tr_d = sum c_n (x_n' G^-1 x_n) x_nd.  Result vector in tmp[], scalar returned.
+  double xk[RR][DPc], tk[RR];
+  if (RPT > 0) {
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const int n = t + 256 * r;
+      const bool in = n < Mp;
+      tk[r] = in ? dd.t[n] : 0.0;
+#pragma unroll
+      for (int d = 0; d < DPc; d += 2) {
+        const double2 q = in ? *(const double2*)(dd.Xr + (size_t)n * DPc + d) : make_double2(0.0, 0.0);
+        xk[r][d] = q.x; xk[r][d + 1] = q.y;
+      }
+    }
+  }
   auto row_pass = [&](int mode, const double* wp, const double* up) -> double {
     double acc[DPc];
 #pragma unroll
     for (int d = 0; d < DPc; ++d) acc[d] = 0.0;
     double lj = 0.0;
-    double xn[DPc];  // next row of this thread, loaded one trip ahead
-    {
-      const double* xr0 = dd.Xr + (size_t)t * DPc;  // t < 256 <= Mp? rows exist up to Mp - 1 >= 63; guard below
-#pragma unroll
-      for (int d = 0; d < DPc; d += 2) { const double2 q = (t < Mp) ? *(const double2*)(xr0 + d) : make_double2(0.0, 0.0); xn[d] = q.x; xn[d + 1] = q.y; }
-    }
-    for (int n = t; n < Mp; n += 256) {
-      double x[DPc];
-      const double* xr = dd.Xr + (size_t)n * DPc;
-#pragma unroll
-      for (int d = 0; d < DPc; ++d) x[d] = xn[d];
-      if (n + 256 < Mp) {
-#pragma unroll
-        for (int d = 0; d < DPc; d += 2) { const double2 q = *(const double2*)(xr + (size_t)256 * DPc + d); xn[d] = q.x; xn[d + 1] = q.y; }
-      }
+    auto one_row = [&](const double (&x)[DPc], double tn, int n) {  // n < Mp
       if (mode <= 1) {
         double f = 0.0;
 #pragma unroll
@@ -104,7 +107,6 @@ __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, doub
         crow[n] = v * (1.0 - 2.0 * p);
         if (mode == 1) {
           const double ef = exp(f);
-          const double tn = dd.t[n];
           if (n < M) lj += f * tn - log(1.0 + ef);
           const double rn = tn - ef / (1.0 + ef);  // padded rows: x = 0, no contribution
 #pragma unroll
@@ -133,6 +135,28 @@ __global__ __launch_bounds__(256) void k_step_medium(DevData dd, Chains ch, doub
         const double z = crow[n] * hn;
 #pragma unroll
         for (int d = 0; d < DPc; ++d) acc[d] = fma(z, x[d], acc[d]);
+      }
+    };
+    if (RPT > 0) {
+#pragma unroll
+      for (int r = 0; r < RR; ++r)
+        if (t + 256 * r < Mp) one_row(xk[r], tk[r], t + 256 * r);
+    } else {
+      double xn[DPc];  // next row of this thread, loaded one trip ahead
+#pragma unroll
+      for (int d = 0; d < DPc; d += 2) {
+        const double2 q = (t < Mp) ? *(const double2*)(dd.Xr + (size_t)t * DPc + d) : make_double2(0.0, 0.0);
+        xn[d] = q.x; xn[d + 1] = q.y;
+      }
+      for (int n = t; n < Mp; n += 256) {
+        double x[DPc];
+#pragma unroll
+        for (int d = 0; d < DPc; ++d) x[d] = xn[d];
+        if (n + 256 < Mp) {
+#pragma unroll
+          for (int d = 0; d < DPc; d += 2) { const double2 q = *(const double2*)(dd.Xr + (size_t)(n + 256) * DPc + d); xn[d] = q.x; xn[d + 1] = q.y; }
+        }
+        one_row(x, mode == 1 ? dd.t[n] : 0.0, n);
       }
     }
     if (mode == 0) { __syncthreads(); return 0.0; }

@@ -400,6 +400,26 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, int
   ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
 }
 
+// one-launch step / evaluation / folded global step for small batches (medium_step.hip.h).  Data rows per thread stay in registers
+// when at most 64 doubles are needed for them.
+template <int NB>
+void launch_step_medium_nb(rmhmc_ctx* ctx, Group& g, hipStream_t st, int guards, int eval_only, int fold, const IterParams& ip) {
+  const int rpt = (ctx->Mp + 255) / 256;
+  const dim3 grid((unsigned)g.n), block(256);
+  const size_t lds = ctx->medium_lds;
+  switch (rpt * 16 * NB <= 64 ? rpt : 0) {
+    case 1: hipLaunchKernelGGL((k_step_medium<NB, 1>), grid, block, lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, eval_only, fold, ip); break;
+    case 2: hipLaunchKernelGGL((k_step_medium<NB, 2>), grid, block, lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, eval_only, fold, ip); break;
+    case 3: hipLaunchKernelGGL((k_step_medium<NB, (NB == 1 ? 3 : 0)>), grid, block, lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, eval_only, fold, ip); break;
+    case 4: hipLaunchKernelGGL((k_step_medium<NB, (NB == 1 ? 4 : 0)>), grid, block, lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, eval_only, fold, ip); break;
+    default: hipLaunchKernelGGL((k_step_medium<NB, 0>), grid, block, lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, eval_only, fold, ip); break;
+  }
+}
+void launch_step_medium(rmhmc_ctx* ctx, Group& g, hipStream_t st, int guards, int eval_only, int fold, const IterParams& ip) {
+  if (ctx->NB == 1) launch_step_medium_nb<1>(ctx, g, st, guards, eval_only, fold, ip);
+  else launch_step_medium_nb<2>(ctx, g, st, guards, eval_only, fold, ip);
+}
+
 // One generalised leapfrog step for every chain in phase 1 (rmhmc.py:96-163).
 void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   const int D = ctx->D, DP = ctx->DP, K = ctx->K;
@@ -408,8 +428,7 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
     ph.push_back([=](Group& g) {
       launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
-        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0, 0, IterParams{});
-        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, eps, K, guards, 0, 0, IterParams{});
+        launch_step_medium(ctx, g, st, guards, 0, 0, IterParams{});
       });
     });
     return;
@@ -532,8 +551,7 @@ void launch_global_step(rmhmc_ctx* ctx, const IterBase& b) {
     for (Group& g : ctx->groups) {
       const IterParams ip = iter_params(ctx, g, b);
       launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
-        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, 0, 1, ip);
-        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, guards, 0, 1, ip);
+        launch_step_medium(ctx, g, st, guards, 0, 1, ip);
       });
     }
     return;
@@ -620,8 +638,7 @@ int eval_at(rmhmc_ctx* ctx, const double* w, const double* p, bool sampler_init 
   if (sampler_init && ctx->medium) {  // same arithmetic as inside the one-launch steps (bit-exact checkpoint / resume)
     for (Group& g : ctx->groups)
       launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
-        if (ctx->NB == 1) hipLaunchKernelGGL((k_step_medium<1>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1, 0, IterParams{});
-        else hipLaunchKernelGGL((k_step_medium<2>), dim3((unsigned)g.n), dim3(256), ctx->medium_lds, st, ctx->dd, g.ch, ctx->eps, ctx->K, 0, 1, 0, IterParams{});
+        launch_step_medium(ctx, g, st, 0, 1, 0, IterParams{});
       });
     return RMHMC_OK;
   }
@@ -817,8 +834,17 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       if (const char* e = getenv("RMHMC_MEDIUM")) on = on && atoi(e) != 0;
       if (on) {
         const size_t lds = sizeof(double) * (ctx->NB == 1 ? ms_lds_doubles<1>(ctx->Mp) : ms_lds_doubles<2>(ctx->Mp));
-        if (ctx->NB == 1) HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (ctx->NB == 1) {
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        } else {
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         ctx->medium = true;
         ctx->medium_lds = lds;
       }
