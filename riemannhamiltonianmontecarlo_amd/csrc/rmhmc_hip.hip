@@ -850,7 +850,11 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       }
     }
     {  // plain HMC in small batches: one launch per trajectory (RMHMC_MEDIUM=0 disables it too)
-      bool on = !ctx->big && D <= 32 && n_chains <= 512;
+      // any batch for short data sets (rows in registers; australian, 8192 chains: 107 M leapfrog-steps/s vs 76 M generic, 2048
+      // chains 90 M vs 27 M, tools/bench_hmc_batch.py), small batches otherwise
+      long long maxn = ctx->Mp <= 1024 ? (1ll << 40) : 512;
+      if (const char* e = getenv("RMHMC_TRAJ_MAXN")) maxn = atoll(e);
+      bool on = !ctx->big && D <= 32 && n_chains <= maxn;
       if (const char* e = getenv("RMHMC_MEDIUM")) on = on && atoi(e) != 0;
       ctx->hmc_traj = on;
     }

@@ -1,0 +1,12 @@
+"""Plain HMC for many chains on the bundled australian data: whole-trajectory kernel vs the generic five-launches-per-step path.
+Run on the GPU box: RMHMC_TRAJ_MAXN=100000 python tools/bench_hmc_batch.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from riemannhamiltonianmontecarlo_amd import HMC
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+d = np.load(os.path.join(GOLDEN, "data_australian.npz"))
+for n in (512, 2048, 8192):
+    w, secs, info = HMC(d["XX"], d["t"], 120, 20, 100, 0.02, n_chains=n, seed=3, verbose=False, return_info=True)
+    steps = int(info["leapfrog_steps"].sum())
+    print("chains %5d: %.3f s post burn-in, %.2f M leapfrog-steps/s, acceptance %.3f" % (n, secs, steps * (100 / 120.0) / secs / 1e6, float(info["accepted"].sum()) / (120 * n)))
