@@ -15,9 +15,16 @@ Workloads (BASELINE.json configs):
   c1  bundled australian data (M=690, D=15), 1 chain
   c5  4096 chains, D=256, M=50000 (large-D path)
 
-Extra objects in the JSON line: "roofline" (dominant kernel = metric assembly, timed with HIP events
-on the library's stream inside the timed region) and "cpu_baseline" (the CPU oracle timed on the
-host cores on a bounded sample; rank 0, N=1 only).
+The timed region runs the product path exactly as a user gets it (the global step replayed from a
+hipGraph, no per-kernel events).  Right after it the SAME K steps are repeated once more with HIP events
+around every launch on the library's stream ("kernel_seconds", un-timed repetition: events disable the
+graph path); the "roofline" object is computed from that repetition.
+
+Extra objects in the JSON line: "roofline" (dominant kernel = metric assembly), "roofline_fp64" (the
+same workload and steps with the metric on the fp64 matrix cores: the same-arithmetic number and its
+fraction of the fp64 MFMA peak), "min_ess" (the second half of BASELINE.json's metric: min-ESS/sec over
+the TimeTaken window of rmhmc.py:194-198, ESS by tools.py:32-74) and "cpu_baseline" (the CPU oracle timed
+on the host cores on a bounded sample; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -90,7 +97,9 @@ def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0, literal_budget_s=10.0):
         with oracle.context(M, D, cores, flags=flags | _capi.FLAG_ORACLE_LITERAL) as ctx:
             ctx.set_data(XX, t)
             t0 = time.perf_counter(); ctx.leapfrog(w, p, eps, 1, 1, K); dtl = time.perf_counter() - t0
-        out["reference_algorithm"] = {"value": cores / dtl, "unit": "leapfrog-steps/s", "cores": cores,
+        out["reference_algorithm"] = {"value": cores / dtl, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+                                      "stands_in_for": "the reference NumPy path (BASELINE.md 3.1): same O(M D^3) algorithm compiled from C, "
+                                                       "so it is FASTER than rmhmc.py's interpreter loop and the GPU/CPU ratio it gives is conservative",
                                       "sample": "%d chains x 1 leapfrog step incl. the set-up block (rmhmc.py:50-77), literal "
                                                 "tensor-forming C restatement of rmhmc.py, %.1f s" % (cores, dtl)}
     return out
@@ -109,8 +118,10 @@ def main():
     ap.add_argument("--no-alternates", action="store_true", help="skip the short extra runs with the other metric-assembly variants")
     ap.add_argument("--compat", type=int, default=0, help="1: reference-compatible momentum (L'z) and guards; 0: corrected (default, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ess-iters", type=int, default=0,
-                    help="if >0: also run RMHMC for this many post-burn-in transitions (+100 burn-in) per chain and report min-ESS/sec")
+    ap.add_argument("--ess-iters", type=int, default=-1,
+                    help="run RMHMC for this many post-burn-in transitions (+100 burn-in) per chain and report min-ESS/sec, the second half of "
+                         "the metric; -1 (default): 200 (c1-c3; config 5 at 1 s per global step: 0 = off), 0: off")
+    ap.add_argument("--no-fp64-roofline", action="store_true", help="skip the extra fp64-matrix-core run behind roofline_fp64")
     args = ap.parse_args()
 
     import torch
@@ -143,13 +154,19 @@ def main():
     M, D = XX.shape
     L, eps, K = 6, 0.5, 4  # reference defaults, rmhmc.py:13
     flags = _capi.COMPAT if args.compat else 0
-    if args.i8_slices < 0:
+    auto_i8 = args.i8_slices < 0
+    if auto_i8:
         args.i8_slices = 6 if (8 < D <= 256 and n * float(M) * D * D >= 1e9) else 0
     gpu_flags = flags | (_capi.int8_metric_flags(args.i8_slices) if args.i8_slices else 0)
+    if auto_i8 and args.i8_slices:
+        gpu_flags |= _capi.FLAG_INT8_CERTIFY   # as the shims do: rmhmc_set_data checks the fixed-point error bound for this data
 
     lib = _capi.load_hip_library()  # raises if the extension is not built
     ctx = lib.context(M, D, n, flags=gpu_flags, device=dev)
     ctx.set_data(XX, t)
+    i8_bound, i8_active = ctx.int8_certificate()
+    if args.i8_slices and not i8_active:   # not certified to 1e-9: the library runs this data on the fp64 matrix cores
+        args.i8_slices = 0
     ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
 
     def barrier():
@@ -159,10 +176,9 @@ def main():
         torch.cuda.synchronize()
 
     ctx.chains_run(args.warmup)
-    ctx.kernel_time("enable"); ctx.kernel_time("reset")
     barrier()
     t0 = time.perf_counter()
-    ctx.chains_run(args.steps)   # synchronous: returns when the device is idle
+    ctx.chains_run(args.steps)   # synchronous: returns when the device is idle.  Product path: graph replay, no events
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -172,39 +188,57 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kt = {k: ctx.kernel_time(k) for k in ("assemble", "assemble_i8", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small", "fused", "medium", "total")}
+    KT_NAMES = ("assemble", "assemble_i8", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small",
+                "fused", "medium", "total")
+    # un-timed repetition of the same K steps with HIP events around every launch (on the library's own stream)
+    ctx.kernel_time("enable"); ctx.kernel_time("reset")
+    tk0 = time.perf_counter(); ctx.chains_run(args.steps); tk1 = time.perf_counter()
+    kt = {k: ctx.kernel_time(k) for k in KT_NAMES}
     ctx.kernel_time("disable")
-    w_end, iters, acc = ctx.chains_state()
-    finite = bool(np.isfinite(w_end).all())
-    acc_rate = float(acc.sum()) / max(1.0, float(iters.sum()))
-
+    finite = True
     if world > 1 or force_dist:
-        # the one exchange of the sharded path: gather the chain positions at write-out (RCCL over xGMI)
-        wt = torch.from_numpy(w_end).to(ddev)
+        # the one exchange of the sharded path: the chain positions are gathered at write-out straight from HBM
+        # (rmhmc_chains_state_dev writes into a torch tensor on this GPU; RCCL sends that buffer over xGMI)
+        wt, it_t, acc_t = ctx.chains_state_dev(torch.device("cuda", dev))
+        if backend != "nccl":
+            wt = wt.to(ddev)
         gathered = [torch.empty_like(wt) for _ in range(world)] if rank == 0 else None
         dist.gather(wt, gathered, dst=0)
         if rank == 0:
-            finite = finite and all(bool(torch.isfinite(g).all()) for g in gathered)
+            finite = all(bool(torch.isfinite(g).all()) for g in gathered)
+            gathered_chains = int(sum(g.shape[0] for g in gathered))
+        iters, acc = it_t.cpu().numpy(), acc_t.cpu().numpy()
+        finite = finite and bool(torch.isfinite(wt).all())
+    else:
+        w_end, iters, acc = ctx.chains_state()
+        finite = bool(np.isfinite(w_end).all())
+        gathered_chains = n
+    acc_rate = float(acc.sum()) / max(1.0, float(iters.sum()))
 
     ess = None
+    if args.ess_iters < 0:
+        args.ess_iters = 0 if args.workload == "c5" else 200
     if args.ess_iters > 0:
         # second half of the metric: sum over chains of (min over dims of the per-chain ESS) / seconds of the
         # post-burn-in phase (TimeTaken semantics, rmhmc.py:194-198).  ESS by tools.CalculateESS semantics with
         # the MATLAB FFT length (no wrap-around); estimated on a subset of chains to bound the host FFT work.
         burn = 100
-        st = ctx.sample_stats(burn + args.ess_iters, burn, L=L, eps=eps, K=K, seed=7, chain_offset=rank * n)
-        me = np.nanmin(st["ess"], axis=1)                       # per chain: min over dimensions
-        tot = float(np.nansum(me)); secs = st["seconds"]; lsteps = float(st["leapfrog_steps"].sum()); acc_n = float(st["accepted"].sum())
+        st = ctx.sample_stats_dev(torch.device("cuda", dev), burn + args.ess_iters, burn, L=L, eps=eps, K=K, seed=7, chain_offset=rank * n)
+        me = torch.nan_to_num(st["ess"], nan=float("inf")).amin(dim=1)        # per chain: min over dimensions
+        me = me[torch.isfinite(me)]
+        tot = float(me.sum()); secs = st["seconds"]; lsteps = float(st["leapfrog_steps"].sum()); acc_n = float(st["accepted"].sum())
         if world > 1:
             tt = torch.tensor([tot, lsteps, acc_n], device=ddev, dtype=torch.float64); dist.all_reduce(tt)
             ts = torch.tensor([secs], device=ddev, dtype=torch.float64); dist.all_reduce(ts, op=dist.ReduceOp.MAX)
             tot, lsteps, acc_n, secs = float(tt[0]), float(tt[1]), float(tt[2]), float(ts[0])
-        ess = {"min_ess_per_sec": tot / secs, "seconds": secs, "post_burn_in_transitions": args.ess_iters,
+        ess = {"min_ess_per_sec": tot / secs, "unit": "min-ESS/s (sum over chains of min_d ESS_d, / TimeTaken)", "seconds": secs,
+               "post_burn_in_transitions": args.ess_iters, "burn_in": burn, "compat": bool(args.compat),
                "mean_min_ess_per_chain": tot / (n * world), "chains": n * world,
                "leapfrog_steps_per_sec_during_sampling": lsteps / secs,
                "acceptance": acc_n / float((burn + args.ess_iters) * n * world),
-               "note": "per-chain ESS (MATLAB CalculateStatistics.m semantics: ESS per chain, min over dimensions), summed over "
-                       "all chains; computed on the device by rmhmc_sample_stats (no sample transfer)"}
+               "note": "per-chain ESS (MATLAB CalculateStatistics.m semantics: ESS per chain, min over dimensions; tools.py:32-74 "
+                       "estimator with linear autocovariances = the MATLAB FFT length, no wrap-around), summed over all chains; seconds = "
+                       "the post-burn-in window of rmhmc.py:194-198; computed on the device by rmhmc_sample_stats_dev (no sample transfer)"}
 
     if rank == 0:
         total_steps = world * n * args.steps
@@ -254,9 +288,11 @@ def main():
                     "fp64_equivalent_tflops": 2.0 * n * M * NP / i_avg / 1e12,
                     "fp64_equivalent_frac_of_fp64_mfma_peak": 2.0 * n * M * NP / i_avg / FP64_MFMA_PEAK,
                     "vsplit_avg_launch_ms": kt["vsplit"][0] / max(1, kt["vsplit"][1]) * 1e3,
-                    "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
+                    "survey8d_streaming_model_frac_NOT_A_BOUND": (value / world) * bytes_step / HBM_PEAK,
                     "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
-                    "note": "achieved = int8 multiply-adds issued for the unpadded problem (chains x D(D+1)/2 pairs x M rows x S(S+1)/2 "
+                    "note": "survey8d_streaming_model_frac = steps/s x 80 M D bytes / 8 TB/s, the figure SURVEY 8(d) / north_star ask for; it can "
+                            "exceed 1 because X is shared by all chains (cache resident), so it is a model, not a physical bound.  "
+                            "achieved = int8 multiply-adds issued for the unpadded problem (chains x D(D+1)/2 pairs x M rows x S(S+1)/2 "
                             "slice products) / measured launch time; fp64_equivalent = the fp64 flops of the same assembly"}
         elif a_n > 0:
             a_avg = a_s / a_n
@@ -268,7 +304,7 @@ def main():
                 roof = {"bound": "mfma", "kernel": "k_assemble_pair (X' diag(v) X, one wave per (chain, 64-column block pair), fp64 MFMA)",
                         "achieved": fl / a_avg / 1e12, "peak": FP64_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / a_avg / FP64_MFMA_PEAK,
                         "traffic": None, "avg_launch_ms": a_avg * 1e3, "launches": a_n,
-                        "alg_hbm_gbs": achieved / 1e9, "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
+                        "alg_hbm_gbs": achieved / 1e9, "survey8d_streaming_model_frac_NOT_A_BOUND": (value / world) * bytes_step / HBM_PEAK,
                         "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
                         "note": "achieved = MFMA flops issued by one assembly launch (all block pairs) / measured launch time"}
             else:
@@ -278,7 +314,7 @@ def main():
                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
                         "avg_launch_ms": a_avg * 1e3, "launches": a_n,
                         "mfma_tflops": fl / a_avg / 1e12, "mfma_frac": fl / a_avg / FP64_MFMA_PEAK,
-                        "step_hbm_frac": (value / world) * bytes_step / HBM_PEAK,
+                        "survey8d_streaming_model_frac_NOT_A_BOUND": (value / world) * bytes_step / HBM_PEAK,
                         "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
                         "note": "achieved = algorithmic bytes (8*M*D per chain per pass) / measured launch time; X is shared by all "
                                 "chains and cache resident, so DRAM traffic is far below the algorithmic bytes (see DESIGN.md)"}
@@ -299,32 +335,66 @@ def main():
             "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
                        "D": D, "M": M, "leapfrog_L": L, "step_size": eps, "fixed_point_K": K,
-                       "compat": bool(args.compat), "metric_assembly": ("int8 x %d slices" % args.i8_slices) if args.i8_slices else "fp64", "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
+                       "compat": bool(args.compat), "metric_assembly": ("int8 x %d slices" % args.i8_slices) if args.i8_slices else "fp64",
+                       "int8_error_certificate": i8_bound if i8_bound > 0 else None, "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "roofline": roof,
             "kernel_seconds": {k: {"seconds": v[0], "launches": v[1]} for k, v in kt.items()},
-            "all_finite": finite, "acceptance_rate": acc_rate,
+            "kernel_seconds_from": "un-timed repetition of the same %d steps with HIP events around every launch (%.1f ms per step there; the "
+                                   "timed region itself runs the hipGraph path without events)" % (args.steps, (tk1 - tk0) / args.steps * 1e3),
+            "all_finite": finite, "acceptance_rate": acc_rate, "gathered_chains": gathered_chains,
         }
+        if roof is not None and roof.get("traffic") is not None:
+            roof["traffic_source"] = "profiles/traffic_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (per launch)" % args.workload
         if ess is not None:
             out["min_ess"] = ess
+            out["min_ess_per_sec"] = ess["min_ess_per_sec"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(XX, t, flags, L, eps, K)
     ctx.close()
     if rank == 0:
-        if world == 1 and not args.no_alternates and 8 < D <= 256 and n * float(M) * D * D >= 1e9:
+        big = 8 < D <= 256 and n * float(M) * D * D >= 1e9
+
+        def run_variant(sl, steps, timing):
+            c2 = lib.context(M, D, n, flags=flags | (_capi.int8_metric_flags(sl) if sl else 0), device=dev)
+            c2.set_data(XX, t)
+            c2.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
+            c2.chains_run(min(args.warmup, 2) or 1)
+            torch.cuda.synchronize(); ta = time.perf_counter()
+            c2.chains_run(steps)
+            torch.cuda.synchronize(); tb = time.perf_counter()
+            k2 = None
+            if timing:
+                c2.kernel_time("enable"); c2.kernel_time("reset")
+                c2.chains_run(steps)
+                k2 = {k: c2.kernel_time(k) for k in KT_NAMES}
+            c2.close()
+            return {"value": n * steps / (tb - ta), "ms_per_step": (tb - ta) / steps * 1e3}, k2
+
+        if world == 1 and big and args.i8_slices and not args.no_fp64_roofline and D <= 64:
+            # the same workload for the same number of steps with the metric on the fp64 matrix cores: the number in the SAME arithmetic
+            # as the reference, with its own roofline (k_assemble: MFMA flops issued / launch time / fp64 MFMA peak)
+            res, k2 = run_variant(0, args.steps, True)
+            a_s2, a_n2 = k2["assemble"]
+            nb16 = (D + 15) // 16
+            fl = n * (M / 4.0) * (nb16 * (nb16 + 1) // 2) * 2048.0
+            a_avg2 = a_s2 / max(1, a_n2)
+            out["roofline_fp64"] = {"value": res["value"], "unit": "leapfrog-steps/s", "ms_per_step": res["ms_per_step"], "steps": args.steps,
+                                    "bound": "mfma", "kernel": "k_assemble (X' diag(v) X on v_mfma_f64_16x16x4_f64, lower-triangle tiles only)",
+                                    "achieved": fl / a_avg2 / 1e12, "peak": FP64_MFMA_PEAK / 1e12, "unit_roofline": "TFLOP/s",
+                                    "frac": fl / a_avg2 / FP64_MFMA_PEAK, "avg_launch_ms": a_avg2 * 1e3, "launches": a_n2,
+                                    "kernel_seconds": {k: {"seconds": v[0], "launches": v[1]} for k, v in k2.items() if v[1]},
+                                    "survey8d_streaming_model_frac_NOT_A_BOUND": res["value"] * bytes_step / HBM_PEAK,
+                                    "note": "dtype f64 in every kernel (no integer slicing); achieved = MFMA flops issued by one assembly launch "
+                                            "(chains x M/4 x 10 tiles x 2048) / its average launch time in an un-timed repetition with events"}
+        if world == 1 and not args.no_alternates and big:
             # the same workload with the other metric-assembly variants, 3 steps each (not the headline)
             alts = {}
             for name, sl in (("fp64_mfma", 0), ("int8_x5", 5), ("int8_x6", 6)):
-                if sl == args.i8_slices:
+                if sl == args.i8_slices or (sl == 0 and "roofline_fp64" in out):
                     continue
-                c2 = lib.context(M, D, n, flags=flags | (_capi.int8_metric_flags(sl) if sl else 0), device=dev)
-                c2.set_data(XX, t)
-                c2.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
-                c2.chains_run(1)
-                torch.cuda.synchronize(); ta = time.perf_counter()
-                c2.chains_run(3)
-                torch.cuda.synchronize(); tb = time.perf_counter()
-                c2.close()
-                alts[name] = {"value": n * 3 / (tb - ta), "ms_per_step": (tb - ta) / 3 * 1e3}
+                alts[name], _ = run_variant(sl, 3, False)
+            if "roofline_fp64" in out:
+                alts["fp64_mfma"] = {"value": out["roofline_fp64"]["value"], "ms_per_step": out["roofline_fp64"]["ms_per_step"]}
             out["alternates"] = alts
         print(json.dumps(out))
     if world > 1 or force_dist:

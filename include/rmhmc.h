@@ -66,6 +66,13 @@ typedef struct rmhmc_ctx rmhmc_ctx;
                                           for any data.  Not used by the fused D <= 8 path; ignored by the oracle,
                                           which is always fp64. */
 #define RMHMC_FLAG_INT8_SLICES(S) (((uint32_t)(S) & 7u) << 12)
+#define RMHMC_FLAG_INT8_CERTIFY (1u << 7) /* with RMHMC_FLAG_INT8_METRIC: rmhmc_set_data evaluates the worst-case error bound of
+                                          the fixed-point assembly for the data it is given (csrc/metric_i8.hip.h, "Error bound";
+                                          e.g. one outlier row 1000x the others coarsens every other row's fixed-point grid) and,
+                                          when it exceeds RMHMC_INT8_CERTIFY_TOL, runs that data set on the fp64 matrix cores
+                                          instead.  Without this bit the int8 path is used unconditionally (explicit request).
+                                          The Python shims set it whenever they choose the int8 path by themselves. */
+#define RMHMC_INT8_CERTIFY_TOL 1e-9
 #define RMHMC_FLAG_MMALA_FULL (1u << 6)  /* rmhmc_mmala_*: the full manifold MALA of BLR_mMALA.m (drift with the metric-
                                           derivative terms) instead of the simplified one of BLR_mMALA_Simp.m */
 #define RMHMC_FLAG_ORACLE_LITERAL (1u << 8) /* oracle only: form the DxDxD
@@ -219,6 +226,28 @@ int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t 
                        uint64_t seed, int64_t chain_offset, const double *theta0, double *mean_out,
                        double *var_out, double *ess_out, int64_t *accept_out, int64_t *steps_out,
                        double *seconds_out);
+
+/* Certificate of the int8 metric path for the data of the last rmhmc_set_data: bound_out = worst-case error of any G_ab
+ * relative to sqrt(G0_aa G0_bb), G0 = X'X/4 + I/alpha (0 when the path was not requested); active_out = 1 when the int8 kernels
+ * are in use, 0 when the path was not requested or RMHMC_FLAG_INT8_CERTIFY sent this data set to the fp64 kernels.  The oracle
+ * reports (0, 0).                                                                                                          */
+int rmhmc_int8_certificate(rmhmc_ctx *ctx, double *bound_out, int32_t *active_out);
+
+/* ---- device-resident write-out ("one RCCL gather over xGMI at sample write-out") -----------------------
+ * The same calls as rmhmc_chains_state / rmhmc_sample / rmhmc_sample_stats with every OUTPUT ARRAY in DEVICE memory of the
+ * context's GPU (plain device pointers, e.g. a torch tensor's data_ptr(); same shapes, same element types, unpadded and
+ * contiguous; each may be NULL).  Nothing crosses PCIe: the sampler saves straight into samples_dev, so that the multi-GPU
+ * driver can hand the buffers to RCCL (ncclGather / all_gather over xGMI) without a host bounce.  Inputs (theta0) and the
+ * scalar seconds_out stay host memory.  The calls are synchronous: the library's stream is idle on return, so any other
+ * stream may read the buffers afterwards.  In the CPU oracle "device" memory is host memory.                              */
+int rmhmc_chains_state_dev(rmhmc_ctx *ctx, double *w_dev, int64_t *iters_dev, int64_t *accept_dev);
+int rmhmc_sample_dev(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                     int64_t chain_offset, const double *theta0, double *samples_dev, int64_t *accept_dev,
+                     int64_t *steps_dev, double *seconds_out);
+int rmhmc_sample_stats_dev(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K,
+                           uint64_t seed, int64_t chain_offset, const double *theta0, double *mean_dev,
+                           double *var_dev, double *ess_dev, int64_t *accept_dev, int64_t *steps_dev,
+                           double *seconds_out);
 
 /* ---- widening, SURVEY.md 8(f)-4: simplified manifold MALA ---------------------------------------------
  * authors_code/Bayes_Log_Reg/MCMC/BLR_mMALA_Simp.m:175-290 (MATLAB only: the Python reference has no mMALA and no

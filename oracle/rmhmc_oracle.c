@@ -1125,3 +1125,28 @@ void rmhmc_destroy(rmhmc_ctx *ctx) {
   }
   free(ctx->X); free(ctx->t); free(ctx);
 }
+
+/* Device-resident write-out of include/rmhmc.h: the oracle has no device, so "device" memory is host memory and the
+ * _dev entry points are the host ones (the world-size-2 gloo tests drive the multi-GPU host logic through them). */
+int rmhmc_chains_state_dev(rmhmc_ctx *ctx, double *w_dev, int64_t *iters_dev, int64_t *accept_dev) {
+  return rmhmc_chains_state(ctx, w_dev, iters_dev, accept_dev);
+}
+int rmhmc_sample_dev(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                     int64_t chain_offset, const double *theta0, double *samples_dev, int64_t *accept_dev,
+                     int64_t *steps_dev, double *seconds_out) {
+  return rmhmc_sample(ctx, n_iter, burn_in, L, eps, K, seed, chain_offset, theta0, samples_dev, accept_dev, steps_dev, seconds_out);
+}
+int rmhmc_sample_stats_dev(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K,
+                           uint64_t seed, int64_t chain_offset, const double *theta0, double *mean_dev,
+                           double *var_dev, double *ess_dev, int64_t *accept_dev, int64_t *steps_dev,
+                           double *seconds_out) {
+  return rmhmc_sample_stats(ctx, n_iter, burn_in, L, eps, K, seed, chain_offset, theta0, mean_dev, var_dev, ess_dev, accept_dev,
+                            steps_dev, seconds_out);
+}
+
+int rmhmc_int8_certificate(rmhmc_ctx *ctx, double *bound_out, int32_t *active_out) {
+  if (!ctx) return RMHMC_ERR_INVALID;
+  if (bound_out) *bound_out = 0.0;   /* the oracle is float64 throughout */
+  if (active_out) *active_out = 0;
+  return RMHMC_OK;
+}

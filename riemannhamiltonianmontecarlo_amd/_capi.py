@@ -17,6 +17,8 @@ COMPAT = FLAG_MOMENTUM_LT | FLAG_GUARDS
 FLAG_FP32_METRIC = 1 << 4
 FLAG_INT8_METRIC = 1 << 5
 FLAG_MMALA_FULL = 1 << 6
+FLAG_INT8_CERTIFY = 1 << 7
+INT8_CERTIFY_TOL = 1e-9
 
 
 def int8_metric_flags(slices=6):
@@ -30,10 +32,14 @@ def auto_metric_flags(D, n_chains, slices=None, M=None):
     """None: 6 slices where the int8 path pays: 8 < D <= 256 and enough work to fill its 128 x 128 tiles, n_chains * M * D^2 >= 1e9
     (measured, tools/i8_threshold.py: 1.3-1.7x over the fp64 matrix cores from 128 chains x 10000 rows x D 64 and from 8192 chains of
     the 690 x 15 australian data upwards; 0.76x at 600 chains x 1000 x 25), or n_chains >= 1024 when M is not given; 0: fp64 cores"""
+    auto = slices is None
     if slices is None:
         big = (n_chains * float(M) * D * D >= 1e9) if M is not None else (n_chains >= 1024)
         slices = 6 if (8 < D <= 256 and big) else 0
-    return int8_metric_flags(slices) if slices else 0
+    if not slices:
+        return 0
+    # chosen by the shim, not by the caller: let rmhmc_set_data check the error bound for the actual data and fall back to fp64
+    return int8_metric_flags(slices) | (FLAG_INT8_CERTIFY if auto else 0)
 
 
 FLAG_ORACLE_LITERAL = 1 << 8
@@ -68,9 +74,15 @@ SIGNATURES = {
     "rmhmc_chains_state": (C.c_int, [C.c_void_p, _dp, _lp, _lp]),
     "rmhmc_chains_restore": (C.c_int, [C.c_void_p, _lp, _lp]),
     "rmhmc_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _lp]),
+    "rmhmc_int8_certificate": (C.c_int, [C.c_void_p, _dp, _ip]),
     "rmhmc_ess": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64, C.c_int32, _dp]),
     "rmhmc_sample_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                      _dp, _dp, _dp, _dp, _lp, _lp, _dp]),
+    "rmhmc_chains_state_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rmhmc_sample_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64,
+                                   C.c_int64, _dp, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
+    "rmhmc_sample_stats_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
+                                         _dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
     "rmhmc_mmala_transition": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_double, _ip, _dp, _dp]),
     "rmhmc_mmala_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_uint64, C.c_int64, _dp, _dp, _lp, _dp]),
     "rmhmc_hmc_transition": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, _ip, _ip, _dp, _dp, _dp, _dp]),
@@ -240,6 +252,44 @@ class Context:
                                              _ptr(steps, _lp), C.cast(C.byref(secs), _dp)))
         return dict(mean=mean, var=var, ess=ess, accepted=acc, leapfrog_steps=steps, seconds=secs.value)
 
+    # ---- device-resident write-out: outputs are torch tensors on the context's GPU (host tensors for the CPU oracle) ----------
+    def _out_tensors(self, shapes, device):
+        """device: a torch.device.  The HIP library writes through device pointers on its own GPU; the oracle's "device" is the host."""
+        import torch
+        return [torch.empty(shape, dtype=dt, device=device) for shape, dt in shapes]
+
+    def chains_state_dev(self, device):
+        import torch
+        w, it, acc = self._out_tensors([((self.n, self.D), torch.float64), ((self.n,), torch.int64), ((self.n,), torch.int64)], device)
+        self._ck(self.lib.rmhmc_chains_state_dev(self._h, w.data_ptr(), it.data_ptr(), acc.data_ptr()))
+        return w, it, acc
+
+    def sample_dev(self, device, n_iter, burn_in, L=6, eps=0.5, K=4, seed=0, chain_offset=0, theta0=None):
+        import torch
+        n, D = self.n, self.D
+        S = int(n_iter) - int(burn_in)
+        if S <= 0:
+            raise ValueError("BurnIn must be < NumOfIterations")
+        th = None if theta0 is None else _f64(np.broadcast_to(theta0, (n, D)))
+        smp, acc, steps = self._out_tensors([((n, S, D), torch.float64), ((n,), torch.int64), ((n,), torch.int64)], device)
+        secs = C.c_double(0.0)
+        self._ck(self.lib.rmhmc_sample_dev(self._h, int(n_iter), int(burn_in), int(L), float(eps), int(K), int(seed), int(chain_offset),
+                                           _ptr(th), smp.data_ptr(), acc.data_ptr(), steps.data_ptr(), C.cast(C.byref(secs), _dp)))
+        return smp, acc, steps, secs.value
+
+    def sample_stats_dev(self, device, n_iter, burn_in, L=6, eps=0.5, K=4, seed=0, chain_offset=0, theta0=None):
+        import torch
+        n, D = self.n, self.D
+        if int(n_iter) - int(burn_in) <= 0:
+            raise ValueError("BurnIn must be < NumOfIterations")
+        th = None if theta0 is None else _f64(np.broadcast_to(theta0, (n, D)))
+        mean, var, ess, acc, steps = self._out_tensors([((n, D), torch.float64)] * 3 + [((n,), torch.int64)] * 2, device)
+        secs = C.c_double(0.0)
+        self._ck(self.lib.rmhmc_sample_stats_dev(self._h, int(n_iter), int(burn_in), int(L), float(eps), int(K), int(seed), int(chain_offset),
+                                                 _ptr(th), mean.data_ptr(), var.data_ptr(), ess.data_ptr(), acc.data_ptr(), steps.data_ptr(),
+                                                 C.cast(C.byref(secs), _dp)))
+        return dict(mean=mean, var=var, ess=ess, accepted=acc, leapfrog_steps=steps, seconds=secs.value)
+
     # ---- simplified mMALA (authors_code/.../BLR_mMALA_Simp.m) -------------------
     def mmala_transition(self, w, z, u_acc, eps=1.0):
         n, D = self.n, self.D
@@ -299,6 +349,12 @@ class Context:
         it = np.ascontiguousarray(iters, dtype=np.int64).reshape(self.n)
         acc = np.ascontiguousarray(accepted, dtype=np.int64).reshape(self.n)
         self._ck(self.lib.rmhmc_chains_restore(self._h, _ptr(it, _lp), _ptr(acc, _lp)))
+
+    def int8_certificate(self):
+        """(bound, active): worst-case error bound of the int8 metric path for the current data, and whether the int8 kernels are in use"""
+        b = C.c_double(0.0); a = C.c_int32(0)
+        self._ck(self.lib.rmhmc_int8_certificate(self._h, C.cast(C.byref(b), _dp), C.cast(C.byref(a), _ip)))
+        return b.value, bool(a.value)
 
     def kernel_time(self, which):
         s = C.c_double(0.0); k = C.c_int64(0)

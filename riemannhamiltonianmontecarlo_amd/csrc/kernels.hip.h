@@ -1488,6 +1488,22 @@ __global__ void k_fill_ll(long long* p, long long v, size_t n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// *out = min(*out, min_c iter[c]): completed transitions of the slowest chain (the sampler's host loop sizes its next batch of global
+// steps from it: a transition takes at least one step, so the slowest chain needs at least limit - min more)
+__global__ void k_min_iter(const long long* __restrict__ iter, size_t n, unsigned long long* __restrict__ out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  unsigned long long m = i < n ? (unsigned long long)iter[i] : ~0ull;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long x = __shfl_xor(m, o);
+    m = x < m ? x : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMin(out, m);
+}
+// a[i] = b[i] - a[i]
+__global__ void k_sub_ll(long long* __restrict__ a, const long long* __restrict__ b, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) a[i] = b[i] - a[i];
+}
 // phase[c] = (nsteps[c] > 0) for the unit leapfrog API
 __global__ void k_set_leapfrog(int n, const int* __restrict__ nsteps, const int* __restrict__ dir, Chains ch) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -8,6 +8,25 @@
 // combined in fp64 in the epilogue.  The truncation error is 2^-(8S-2) of max|v| max|z| per term: S = 5 gives a norm-wise
 // error of 2e-12 on G at config 3, S = 6 1e-14 (the level of fp64 summation itself); see DESIGN.md and tools/i8_sweep.py.
 //
+// Error bound (what tests/test_gpu_int8_stress.py asserts and what RMHMC_FLAG_INT8_CERTIFY checks in rmhmc_set_data).
+//   Fixed-point grids: v in [0, 1/4] is rounded to a multiple of 2^-8S (ABSOLUTE grid, the same for every chain: |dv| <= 2^-(8S+1));
+//   z_n,ab = x_na x_nb to a multiple of 2^(e_ab-8S+2), 2^e_ab > max_n |z_n,ab| (one exponent per column pair: |dz| <= 2^(e_ab-8S+1)).
+//   The integer GEMM is exact for the slice products it keeps (i + j < S); the dropped ones are at most
+//   (S-1) 2^14 256^(S-2) grid units per term.  Per data row n, with v <= 2^-2 and |z| < 2^e_ab:
+//       |d(v z)|  <=  v |dz| + |z| |dv| + dropped  <=  2^(e_ab-8S-1) + 2^(e_ab-8S-1) + (S-1) 2^(e_ab-8S)  =  S 2^(e_ab-8S)
+//   hence, for ANY chain state,
+//       |dG_ab|  <=  S M 2^(e_ab-8S)            (worst case; rounding errors are sign-random, the typical error is ~sqrt(M) smaller)
+//   The bound scales with the columns like G_ab itself (e_ab follows the scale of x_a x_b), so badly scaled columns and an all-ones
+//   intercept cost nothing.  What does cost: a data row far larger than the others raises e_ab for its pairs and coarsens the grid of
+//   every other row.  The certificate  max_ab S M 2^(e_ab-8S) / sqrt(G0_aa G0_bb),  G0 = X'X/4 + I/alpha (the metric at w = 0),  is
+//   evaluated by rmhmc_set_data: 3e-12 for N(0,1) data at M = 10^4, S = 6; 1.4e-8 with one row 1000x the rest, which
+//   RMHMC_FLAG_INT8_CERTIFY sends to the fp64 kernels (tolerance 1e-9).  At a state whose mean curvature vbar = mean(v) is below 1/4
+//   the data part of G shrinks and the relative bound grows by 1/(4 vbar), until the prior floor: G >= I/alpha always, so
+//   |dG_ab| alpha <= S M 2^(e_ab-8S) alpha (7e-7 worst case / ~1e-10 typical at config 3) is the bound for a fully saturated
+//   chain (all |x_n.w| > 30: v below the absolute grid, G = I/alpha + O(1e-9)).
+//   Leverage pass: Q = G^-1 entries carry the CHAIN's exponent and Z the DATA ROW's, so h_n is accurate relative to
+//   max|G^-1| max_ab|x_na x_nb| for every (chain, row) pair: |dh_n| <= S NP 2^(eq_c + ez_n + 4 - 8S), NP = D(D+1)/2.
+//
 // Operand layout in HBM ("stage major": the tile one workgroup needs for one k-stage of 32 data rows is contiguous):
 //     Vs[S][nks][nCp][32]  int8     chains,       nCp = chains rounded up to 128
 //     Zs[S][nks][NPp][32]  int8     column pairs, NPp = D(D+1)/2 rounded up to the tile width

@@ -25,7 +25,10 @@
 
 namespace {
 
-char g_err[512] = "";
+thread_local char g_err[512] = "";  // message of a failed rmhmc_create (no context exists yet); per host thread
+// hipFuncAttributeMaxDynamicSharedMemorySize is per (function, device), not per context: always raise it to the hardware
+// limit, so that two live contexts of different shapes cannot lower each other's launch limit
+constexpr int MAX_LDS = 160 * 1024;
 
 struct EvPair { hipEvent_t a, b; };
 
@@ -87,6 +90,8 @@ struct rmhmc_ctx {
   double* d_zscale = nullptr;
   int i8_nkp = 0, i8_NRp = 0;
   I8Pairs pairs{};
+  bool i8_requested = false;   // RMHMC_FLAG_INT8_METRIC given at create (i8 may be switched off by the set_data certificate)
+  double i8_bound = 0.0;       // certificate of the last set_data (metric_i8.hip.h: "Error bound"), 0 when the path is not requested
   // sampler parameters of the stateful API
   int L = 6, K = 4;
   double eps = 0.5;
@@ -96,6 +101,7 @@ struct rmhmc_ctx {
   double *d_z = nullptr, *d_ulen = nullptr, *d_gdir = nullptr, *d_uacc = nullptr;
   int *d_nsteps = nullptr, *d_dir = nullptr, *d_done = nullptr;
   long long* d_steps0 = nullptr;
+  unsigned long long* d_miniter = nullptr;
   // timing
   bool timing = false;
   std::map<std::string, std::vector<EvPair>> events;
@@ -774,6 +780,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       const int S = i8_slices;
       ctx->i8_chunk = std::max(1, (int)(2147483647.0 / (S * 16384.0)) / 32);
       ctx->i8 = true;
+      ctx->i8_requested = true;
       ctx->i8S = S;
       ctx->i8_bn = S <= 6 ? 128 : 64;
       ctx->i8_nks = (int)((M + 31) / 32);
@@ -816,17 +823,19 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       I8_SWITCH(ctx, {
         constexpr int lds = i8_lds_bytes<S_, WN_, TN_>();
         auto kfn = k_assemble_i8<S_, WN_, TN_>;
-        HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         auto kfn2 = k_leverage_i8<S_, WN_, TN_>;
-        HIPCK(hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCK(hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
       });
     }
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     if (ctx->big) {
       RC(dalloc(ctx, &ctx->d_Wd, n * (size_t)ctx->nbk * 4096));
+      // (the fp64 leverage pass of the large-D path; with the int8 path it is allocated only if the certificate sends set_data back to fp64)
       if (!(flags & RMHMC_FLAG_INT8_METRIC)) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * n * Mp));
     }
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
+    RC(dalloc(ctx, &ctx->d_miniter, 1));
     {  // mid-size problems in small batches: one launch per leapfrog step (RMHMC_MEDIUM=0 disables it)
       // measured per global step at one chain (tools/bench_single.py): australian (D = 15) 108 us vs 218 us generic, heart (D = 14)
       // 85 vs 154, german (D = 25) 236 vs 386
@@ -835,15 +844,15 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       if (on) {
         const size_t lds = sizeof(double) * (ctx->NB == 1 ? ms_lds_doubles<1>(ctx->Mp) : ms_lds_doubles<2>(ctx->Mp));
         if (ctx->NB == 1) {
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         } else {
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+          HIPCK(hipFuncSetAttribute((const void*)k_step_medium<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         }
         ctx->medium = true;
         ctx->medium_lds = lds;
@@ -863,7 +872,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       bool on = (D <= FS_D) && lds <= 160 * 1024;
       if (const char* e = getenv("RMHMC_FUSED")) on = on && atoi(e) != 0;
       if (on) {
-        HIPCK(hipFuncSetAttribute((const void*)k_fused_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCK(hipFuncSetAttribute((const void*)k_fused_small, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         ctx->fused = true;
         ctx->fused_lds = lds;
       }
@@ -903,6 +912,12 @@ int rmhmc_device_info(rmhmc_ctx* ctx, char* buf, size_t len) {
   snprintf(buf, len, "%s %s, %d CUs, %.0f MHz, %.1f GiB; M=%lld (padded %d) D=%d (padded %d, %d MFMA tiles) chains=%lld in %d group(s)%s",
            prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0,
            (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n, (int)ctx->groups.size(), ctx->fused ? ", fused small-problem path" : "");
+  if (ctx->i8_requested) {
+    const size_t k = strlen(buf);
+    snprintf(buf + k, len > k ? len - k : 0, "; int8 metric path %d slices: %s (certificate %.2e%s)", ctx->i8S,
+             ctx->i8 ? "active" : "NOT certified for this data, fp64 matrix cores used", ctx->i8_bound,
+             ctx->have_data ? "" : ", no data yet");
+  }
   return RMHMC_OK;
 }
 
@@ -921,7 +936,7 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
   HIPCK(hipMemcpyAsync((void*)ctx->dd.Xr, xr.data(), xr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCK(hipMemcpyAsync((void*)ctx->dd.Xt, xt.data(), xt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCK(hipMemcpyAsync((void*)ctx->dd.t, tt.data(), tt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->i8) {  // fixed operand of the int8 metric path: slices of x_a x_b for every column pair
+  if (ctx->i8_requested) {  // fixed operand of the int8 metric path: slices of x_a x_b for every column pair
     hipLaunchKernelGGL(k_zmax, dim3((unsigned)ctx->pairs.NPp), dim3(256), 0, ctx->stream, ctx->dd.Xt, (int)M, (int)Mp, ctx->pairs, ctx->d_ze,
                        (double*)ctx->pairs.scale);
     const dim3 grid((unsigned)((ctx->i8_nks * 8 + 255) / 256), (unsigned)ctx->pairs.NPp);
@@ -935,6 +950,24 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
     HIPCK(hipGetLastError());
   }
   RC(sync(ctx));
+  if (ctx->i8_requested) {
+    // Certificate of the fixed-point assembly for THIS data (metric_i8.hip.h, "Error bound"): worst-case error of G_ab relative to
+    // sqrt(G0_aa G0_bb), G0 = X'X/4 + I/alpha (the metric at w = 0), maximised over the column pairs.
+    std::vector<int> ze(ctx->pairs.NP);
+    HIPCK(hipMemcpy(ze.data(), ctx->d_ze, sizeof(int) * ze.size(), hipMemcpyDeviceToHost));
+    std::vector<double> g0(D, 1.0 / alpha);
+    for (size_t n = 0; n < M; ++n)
+      for (size_t d = 0; d < D; ++d) g0[d] += 0.25 * X[n * D + d] * X[n * D + d];
+    double bound = 0.0;
+    for (size_t a = 0, q = 0; a < D; ++a)
+      for (size_t b = 0; b <= a; ++b, ++q)
+        bound = std::max(bound, std::ldexp((double)ctx->i8S * (double)M, ze[q] - 8 * ctx->i8S) / std::sqrt(g0[a] * g0[b]));
+    ctx->i8_bound = bound;
+    const bool ok = !(ctx->flags & RMHMC_FLAG_INT8_CERTIFY) || bound <= RMHMC_INT8_CERTIFY_TOL;
+    if (!ok && ctx->big && !ctx->d_hpart) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * ctx->n * Mp));
+    ctx->i8 = ok;  // not certified: this data set runs on the fp64 matrix cores (same context, same results to fp64 rounding)
+    RC(sync(ctx));
+  }
   ctx->alpha = alpha;
   ctx->dd.inv_alpha = 1.0 / alpha;
   ctx->dd.log_prior_const = -0.5 * std::log(2.0 * M_PI * alpha);
@@ -1132,51 +1165,53 @@ static void run_generic_steps(rmhmc_ctx* ctx, const IterBase& ib, long long nste
   }
 }
 
+// number of chains that reached the iteration limit and the completed transitions of the slowest chain, in one round trip
+static int poll_progress(rmhmc_ctx* ctx, int* done, long long* min_iter) {
+  join_streams(ctx);
+  HIPCK(hipMemsetAsync(ctx->d_miniter, 0xff, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(k_min_iter, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ch.iter, (size_t)ctx->n, ctx->d_miniter);
+  unsigned long long mi = 0;
+  HIPCK(hipMemcpyAsync(done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCK(hipMemcpyAsync(&mi, ctx->d_miniter, sizeof(mi), hipMemcpyDeviceToHost, ctx->stream));
+  RC(sync(ctx));
+  *min_iter = (long long)mi;
+  return RMHMC_OK;
+}
+
 static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_steps) {
-  // every chain needs at least min_steps more global steps; afterwards poll the done counter
+  // Every chain needs at least min_steps more global steps.  Afterwards the host looks at the device state and issues, each time,
+  // as many steps as the slowest chain is certain to need: (limit - its completed transitions), a transition taking >= 1 step.
+  // The remaining work shrinks geometrically (a transition averages (L+1)/2 steps), so a run costs O(log) host round trips
+  // instead of one per 4 steps (thousands of syncs inside the TimeTaken window of the one-launch paths).
   int done = 0;
-  long long s = 0;
-  const int poll = 4;
-  fork_streams(ctx);
-  if (ctx->fused && ctx->sampler == 0) {  // one launch for the guaranteed part, then short launches until every chain is done
-    launch_fused(ctx, ib, min_steps);
-    s = min_steps;
-    for (;;) {
-      join_streams(ctx);
-      HIPCK(hipMemcpyAsync(&done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      RC(sync(ctx));
-      if (done >= ctx->n) return RMHMC_OK;
-      fork_streams(ctx);
-      launch_fused(ctx, ib, 4 * poll);
-      s += 4 * poll;
-      if (s > min_steps * (long long)ctx->L + 1000000) return fail(ctx, RMHMC_ERR_RUNTIME, "sampler did not terminate");
-    }
-  }
+  long long s = min_steps, min_iter = 0;
+  const long long poll = 4;
+  const bool fused = ctx->fused && ctx->sampler == 0;
   StepGraph sg;
-  if (step_graph_usable(ctx, min_steps)) (void)build_step_graph(ctx, ib, sg);
-  run_generic_steps(ctx, ib, min_steps, &sg);
-  s = min_steps;
+  fork_streams(ctx);
+  if (fused) {
+    launch_fused(ctx, ib, min_steps);
+  } else {
+    if (step_graph_usable(ctx, min_steps)) (void)build_step_graph(ctx, ib, sg);
+    run_generic_steps(ctx, ib, min_steps, &sg);
+  }
   for (;;) {
-    join_streams(ctx);
-    HIPCK(hipMemcpyAsync(&done, ctx->d_done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    RC(sync(ctx));
+    RC(poll_progress(ctx, &done, &min_iter));
     if (done >= ctx->n) break;
+    const long long next = std::max(poll, ib.limit - min_iter);
     fork_streams(ctx);
-    run_generic_steps(ctx, ib, poll, &sg);
-    s += poll;
+    if (fused) launch_fused(ctx, ib, next);
+    else run_generic_steps(ctx, ib, next, &sg);
+    s += next;
     if (s > min_steps * (long long)ctx->L + 1000000) return fail(ctx, RMHMC_ERR_RUNTIME, "sampler did not terminate");
   }
   return RMHMC_OK;
 }
 
-// Runs the sampler and leaves the saved states in a freshly allocated device buffer *d_samples_out
-// ([n][S][D]); the caller frees it.
-static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const double* theta0, double** d_samples_out,
-                       int64_t* accept_out, int64_t* steps_out, double* seconds_out) {
+// Runs the sampler; the saved states go to the device buffer d_samples ([n][S][D], caller-provided).  Per-chain counters are left
+// on the device: ch.accepted, and the post-burn-in leapfrog steps in d_steps0 (steps_done at the end minus at the burn-in mark).
+static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const double* theta0, double* d_samples, double* seconds_out) {
   const long long S = n_iter - burn_in;
-  double* d_samples = nullptr;
-  HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
-  *d_samples_out = d_samples;
   RC(init_chains(ctx, theta0));
   // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
   // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
@@ -1192,43 +1227,52 @@ static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const do
   }
   RC(sync(ctx));
   if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  std::vector<long long> a(ctx->n), s1(ctx->n), s0(ctx->n);
-  RC(download(ctx, a.data(), ctx->ch.accepted, ctx->n));
-  RC(download(ctx, s1.data(), ctx->ch.steps_done, ctx->n));
-  RC(download(ctx, s0.data(), ctx->d_steps0, ctx->n));
-  RC(sync(ctx));
-  for (int64_t c = 0; c < ctx->n; ++c) {
-    if (accept_out) accept_out[c] = a[c];
-    if (steps_out) steps_out[c] = s1[c] - s0[c];
-  }
+  hipLaunchKernelGGL(k_sub_ll, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_steps0, ctx->ch.steps_done, (size_t)ctx->n);
+  return RMHMC_OK;
+}
+// the counters of sample_core to host or device int64 arrays (either may be NULL)
+static int sample_counters(rmhmc_ctx* ctx, int64_t* accept_out, int64_t* steps_out, hipMemcpyKind kind) {
+  static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+  if (accept_out) HIPCK(hipMemcpyAsync(accept_out, ctx->ch.accepted, sizeof(int64_t) * ctx->n, kind, ctx->stream));
+  if (steps_out) HIPCK(hipMemcpyAsync(steps_out, ctx->d_steps0, sizeof(int64_t) * ctx->n, kind, ctx->stream));
   return RMHMC_OK;
 }
 
-int rmhmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
-                 int64_t chain_offset, const double* theta0, double* samples_out, int64_t* accept_out, int64_t* steps_out,
-                 double* seconds_out) {
+static int sample_impl(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed, int64_t chain_offset,
+                       const double* theta0, double* samples_out, int64_t* accept_out, int64_t* steps_out, double* seconds_out, bool dev) {
   NEED_DATA(ctx);
   if (!samples_out || burn_in < 0 || burn_in >= n_iter || L < 1 || K < 1)
     return fail(ctx, RMHMC_ERR_INVALID, "sample: need samples_out, 0 <= burn_in < n_iter, L >= 1, K >= 1");
   ctx->chains_ready = false;
   ctx->L = L; ctx->eps = eps; ctx->K = K; ctx->seed = seed; ctx->chain_offset = chain_offset;
-  double* d_samples = nullptr;
-  int rc = sample_core(ctx, n_iter, burn_in, theta0, &d_samples, accept_out, steps_out, seconds_out);
-  if (rc == RMHMC_OK) {
-    rc = [&]() -> int {
-      HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * (size_t)ctx->n * (n_iter - burn_in) * ctx->D, hipMemcpyDeviceToHost, ctx->stream));
-      return sync(ctx);
-    }();
-  }
-  if (d_samples) (void)hipFree(d_samples);
+  const size_t count = (size_t)ctx->n * (n_iter - burn_in) * ctx->D;
+  double* d_samples = dev ? samples_out : nullptr;  // device-resident write-out: the sampler saves straight into the caller's HBM buffer
+  if (!dev) HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * count));
+  int rc = [&]() -> int {
+    RC(sample_core(ctx, n_iter, burn_in, theta0, d_samples, seconds_out));
+    if (!dev) HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    RC(sample_counters(ctx, accept_out, steps_out, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return sync(ctx);
+  }();
+  if (!dev && d_samples) (void)hipFree(d_samples);
   return rc;
+}
+
+int rmhmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                 int64_t chain_offset, const double* theta0, double* samples_out, int64_t* accept_out, int64_t* steps_out,
+                 double* seconds_out) {
+  return sample_impl(ctx, n_iter, burn_in, L, eps, K, seed, chain_offset, theta0, samples_out, accept_out, steps_out, seconds_out, false);
+}
+int rmhmc_sample_dev(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                     int64_t chain_offset, const double* theta0, double* samples_dev, int64_t* accept_dev, int64_t* steps_dev,
+                     double* seconds_out) {
+  return sample_impl(ctx, n_iter, burn_in, L, eps, K, seed, chain_offset, theta0, samples_dev, accept_dev, steps_dev, seconds_out, true);
 }
 
 // ---- ESS / posterior summaries on the device (tools.py:32-74) -------------------------------------------
 static int launch_ess(rmhmc_ctx* ctx, const double* d_samples, long long nblocks, long long S, int P, double* d_ess, double* d_mean, double* d_var) {
   if (S < 2 || S > 20000) return fail(ctx, RMHMC_ERR_UNSUPPORTED, "ess: 2 <= S <= 20000 samples per chain (the centred series is held in LDS)");
-  static bool attr_set = false;
-  if (!attr_set) { HIPCK(hipFuncSetAttribute((const void*)k_ess, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+  HIPCK(hipFuncSetAttribute((const void*)k_ess, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));  // per device: set where it is used
   hipLaunchKernelGGL(k_ess, dim3((unsigned)(nblocks * P)), dim3(64), (size_t)S * sizeof(double), ctx->stream, d_samples, S, P, d_ess, d_mean, d_var);
   return RMHMC_OK;
 }
@@ -1250,9 +1294,9 @@ int rmhmc_ess(rmhmc_ctx* ctx, const double* samples, int64_t n, int64_t S, int32
   return rc;
 }
 
-int rmhmc_sample_stats(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
-                       int64_t chain_offset, const double* theta0, double* mean_out, double* var_out, double* ess_out,
-                       int64_t* accept_out, int64_t* steps_out, double* seconds_out) {
+static int sample_stats_impl(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                             int64_t chain_offset, const double* theta0, double* mean_out, double* var_out, double* ess_out,
+                             int64_t* accept_out, int64_t* steps_out, double* seconds_out, bool dev) {
   NEED_DATA(ctx);
   if (burn_in < 0 || burn_in >= n_iter || L < 1 || K < 1)
     return fail(ctx, RMHMC_ERR_INVALID, "sample_stats: need 0 <= burn_in < n_iter, L >= 1, K >= 1");
@@ -1261,21 +1305,34 @@ int rmhmc_sample_stats(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t 
   const long long S = n_iter - burn_in;
   double* d_samples = nullptr;
   double* d_out = nullptr;  // [3][n][D]: ess, mean, var
-  int rc = sample_core(ctx, n_iter, burn_in, theta0, &d_samples, accept_out, steps_out, seconds_out);
-  if (rc == RMHMC_OK) {
-    rc = [&]() -> int {
-      const size_t nd = (size_t)ctx->n * ctx->D;
-      HIPCK(hipMalloc((void**)&d_out, sizeof(double) * 3 * nd));
-      RC(launch_ess(ctx, d_samples, ctx->n, S, ctx->D, d_out, d_out + nd, d_out + 2 * nd));
-      if (ess_out) RC(download(ctx, ess_out, d_out, nd));
-      if (mean_out) RC(download(ctx, mean_out, d_out + nd, nd));
-      if (var_out) RC(download(ctx, var_out, d_out + 2 * nd, nd));
-      return sync(ctx);
-    }();
-  }
+  HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
+  int rc = [&]() -> int {
+    RC(sample_core(ctx, n_iter, burn_in, theta0, d_samples, seconds_out));
+    const size_t nd = (size_t)ctx->n * ctx->D;
+    HIPCK(hipMalloc((void**)&d_out, sizeof(double) * 3 * nd));
+    RC(launch_ess(ctx, d_samples, ctx->n, S, ctx->D, d_out, d_out + nd, d_out + 2 * nd));
+    const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (ess_out) HIPCK(hipMemcpyAsync(ess_out, d_out, sizeof(double) * nd, kind, ctx->stream));
+    if (mean_out) HIPCK(hipMemcpyAsync(mean_out, d_out + nd, sizeof(double) * nd, kind, ctx->stream));
+    if (var_out) HIPCK(hipMemcpyAsync(var_out, d_out + 2 * nd, sizeof(double) * nd, kind, ctx->stream));
+    RC(sample_counters(ctx, accept_out, steps_out, kind));
+    return sync(ctx);
+  }();
   if (d_samples) (void)hipFree(d_samples);
   if (d_out) (void)hipFree(d_out);
   return rc;
+}
+int rmhmc_sample_stats(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                       int64_t chain_offset, const double* theta0, double* mean_out, double* var_out, double* ess_out,
+                       int64_t* accept_out, int64_t* steps_out, double* seconds_out) {
+  return sample_stats_impl(ctx, n_iter, burn_in, L, eps, K, seed, chain_offset, theta0, mean_out, var_out, ess_out, accept_out, steps_out,
+                           seconds_out, false);
+}
+int rmhmc_sample_stats_dev(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L, double eps, int32_t K, uint64_t seed,
+                           int64_t chain_offset, const double* theta0, double* mean_dev, double* var_dev, double* ess_dev,
+                           int64_t* accept_dev, int64_t* steps_dev, double* seconds_out) {
+  return sample_stats_impl(ctx, n_iter, burn_in, L, eps, K, seed, chain_offset, theta0, mean_dev, var_dev, ess_dev, accept_dev, steps_dev,
+                           seconds_out, true);
 }
 
 // ---- plain HMC (code/hmc.py) -------------------------------------------------------------------------
@@ -1341,10 +1398,11 @@ int rmhmc_hmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L,
   if (!samples_out || burn_in < 0 || burn_in >= n_iter || L < 1)
     return fail(ctx, RMHMC_ERR_INVALID, "hmc_sample: need samples_out, 0 <= burn_in < n_iter, L >= 1");
   ctx->chains_ready = false;
-  ctx->L = L; ctx->eps = eps; ctx->seed = seed; ctx->chain_offset = chain_offset; ctx->sampler = 1;
+  ctx->L = L; ctx->eps = eps; ctx->seed = seed; ctx->chain_offset = chain_offset;
   const long long S = n_iter - burn_in;
   double* d_samples = nullptr;
   HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
+  ctx->sampler = 1;  // (after the allocation: an early return above must not leave the context in HMC mode)
   int rc = [&]() -> int {
     RC(hmc_init_chains(ctx, theta0));
     const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
@@ -1483,14 +1541,22 @@ int rmhmc_chains_run(rmhmc_ctx* ctx, int64_t n_steps) {
   return sync(ctx);
 }
 
-int rmhmc_chains_state(rmhmc_ctx* ctx, double* w_out, int64_t* iters_out, int64_t* accept_out) {
+static int chains_state_impl(rmhmc_ctx* ctx, double* w_out, int64_t* iters_out, int64_t* accept_out, bool dev) {
   NEED_DATA(ctx);
   if (!ctx->chains_ready) return fail(ctx, RMHMC_ERR_INVALID, "chains_state: rmhmc_chains_init has not been called");
-  if (w_out) RC(download_vec(ctx, w_out, ctx->ch.cur.w));
+  const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (w_out)  // strip the padding: [n][DP] -> [n][D]
+    HIPCK(hipMemcpy2DAsync(w_out, ctx->D * sizeof(double), ctx->ch.cur.w, ctx->DP * sizeof(double), ctx->D * sizeof(double), ctx->n, kind, ctx->stream));
   static_assert(sizeof(long long) == sizeof(int64_t), "int64");
-  if (iters_out) RC(download(ctx, (long long*)iters_out, ctx->ch.iter, ctx->n));
-  if (accept_out) RC(download(ctx, (long long*)accept_out, ctx->ch.accepted, ctx->n));
+  if (iters_out) HIPCK(hipMemcpyAsync(iters_out, ctx->ch.iter, sizeof(int64_t) * ctx->n, kind, ctx->stream));
+  if (accept_out) HIPCK(hipMemcpyAsync(accept_out, ctx->ch.accepted, sizeof(int64_t) * ctx->n, kind, ctx->stream));
   return sync(ctx);
+}
+int rmhmc_chains_state(rmhmc_ctx* ctx, double* w_out, int64_t* iters_out, int64_t* accept_out) {
+  return chains_state_impl(ctx, w_out, iters_out, accept_out, false);
+}
+int rmhmc_chains_state_dev(rmhmc_ctx* ctx, double* w_dev, int64_t* iters_dev, int64_t* accept_dev) {
+  return chains_state_impl(ctx, w_dev, iters_dev, accept_dev, true);
 }
 
 int rmhmc_chains_restore(rmhmc_ctx* ctx, const int64_t* iters, const int64_t* accepted) {
@@ -1501,6 +1567,13 @@ int rmhmc_chains_restore(rmhmc_ctx* ctx, const int64_t* iters, const int64_t* ac
   RC(upload(ctx, ctx->ch.iter, (const long long*)iters, ctx->n));
   RC(upload(ctx, ctx->ch.accepted, (const long long*)accepted, ctx->n));
   return sync(ctx);
+}
+
+int rmhmc_int8_certificate(rmhmc_ctx* ctx, double* bound_out, int32_t* active_out) {
+  if (!ctx) return fail(nullptr, RMHMC_ERR_INVALID, "int8_certificate: null context");
+  if (bound_out) *bound_out = ctx->i8_bound;
+  if (active_out) *active_out = (ctx->i8_requested && ctx->i8) ? 1 : 0;
+  return RMHMC_OK;
 }
 
 int rmhmc_kernel_time(rmhmc_ctx* ctx, const char* which, double* seconds_out, int64_t* launches_out) {

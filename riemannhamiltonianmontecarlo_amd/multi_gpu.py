@@ -5,7 +5,8 @@ partitions by chain index: rank r runs chains ``[start_r, end_r)`` on its own GP
 its own ``rmhmc_set_data`` and **no collective inside the sampling loop**.  The Philox counters use the
 global chain id (``chain_offset``), so the samples do not depend on the number of ranks.  The single
 exchange is the gather at write-out (``torch.distributed``: RCCL over xGMI for the ``nccl`` backend, gloo
-in the CPU tests).  One process per GPU, launched by ``torch.distributed.run``.
+in the CPU tests), fed from device memory: the sampler writes its outputs through the ``_dev`` entry points of
+include/rmhmc.h into torch tensors in HBM and those tensors are what RCCL sends.  One process per GPU, launched by ``torch.distributed.run``.
 """
 import os
 
@@ -28,20 +29,24 @@ def _dist():
     return dist
 
 
-def _gather_rows(local, counts, device):
-    """Gather variable-length leading-dimension arrays to rank 0 (padding to the longest shard)."""
+def _gather_rows(local, counts):
+    """Gather variable-length leading-dimension TENSORS to rank 0, padding to the longest shard.  `local` lives where the
+    collective runs: in HBM for the nccl backend (RCCL moves it over xGMI straight from the buffer the sampler wrote - no host
+    bounce), in host memory for gloo.  Rank 0 gets one tensor on the same device, other ranks None."""
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     mx = max(counts)
-    pad = np.zeros((mx,) + local.shape[1:], dtype=local.dtype)
-    pad[: local.shape[0]] = local
-    tl = torch.from_numpy(pad).to(device)
-    bufs = [torch.empty_like(tl) for _ in range(world)] if rank == 0 else None
-    dist.gather(tl, bufs, dst=0)
+    if local.shape[0] != mx:
+        pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        local = pad
+    local = local.contiguous()
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, bufs, dst=0)
     if rank != 0:
         return None
-    return np.concatenate([b.cpu().numpy()[: counts[r]] for r, b in enumerate(bufs)], axis=0)
+    return torch.cat([b[: counts[r]] for r, b in enumerate(bufs)], dim=0)
 
 
 def sample_sharded(XX, t, n_chains, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=6, StepSize=0.5,
@@ -66,35 +71,41 @@ def sample_sharded(XX, t, n_chains, NumOfIterations=6000, BurnIn=1000, NumOfLeap
     counts = [shard_range(n_chains, world, r)[1] - shard_range(n_chains, world, r)[0] for r in range(world)]
     n_local = end - start
     S = NumOfIterations - BurnIn
-    summ = None
+    import torch as _t
     if n_local > 0:
         th = None if theta0 is None else np.broadcast_to(theta0, (n_chains, D))[start:end]
         with lib.context(N, D, n_local, flags=(_capi.COMPAT if compat else 0) | _capi.auto_metric_flags(D, n_local, M=N), device=local_rank if backend == "nccl" else 0) as ctx:
             ctx.set_data(XX, t, alpha)
+            # device-resident write-out (rmhmc_sample_dev / rmhmc_sample_stats_dev): the outputs stay in this rank's HBM
             if gather == "samples":
-                smp, acc, steps, secs = ctx.sample(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps,
-                                                   seed=seed, chain_offset=start, theta0=th)
-            else:  # reduced on the device: no sample transfer at all (rmhmc_sample_stats)
-                st = ctx.sample_stats(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps, seed=seed,
-                                      chain_offset=start, theta0=th)
+                smp, acc, steps, secs = ctx.sample_dev(device, NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps,
+                                                       seed=seed, chain_offset=start, theta0=th)
+                summ = None
+            else:  # reduced on the device: no raw sample leaves the GPU at all
+                st = ctx.sample_stats_dev(device, NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps, seed=seed,
+                                          chain_offset=start, theta0=th)
                 acc, steps, secs = st["accepted"], st["leapfrog_steps"], st["seconds"]
-                summ = np.concatenate([st["mean"], st["var"], np.nanmin(st["ess"], axis=1, keepdims=True)], axis=1)
-                smp = np.zeros((n_local, 0, D))
+                ess = _t.nan_to_num(st["ess"], nan=float("inf")).amin(dim=1, keepdim=True)   # nanmin over the dimensions
+                summ = _t.cat([st["mean"], st["var"], ess], dim=1)
+                smp = None
     else:
-        smp = np.zeros((0, S, D)); acc = np.zeros(0, dtype=np.int64); steps = np.zeros(0, dtype=np.int64); secs = 0.0
-        summ = np.zeros((0, 2 * D + 1))
+        smp = _t.zeros((0, S, D), dtype=_t.float64, device=device)
+        acc = _t.zeros(0, dtype=_t.int64, device=device); steps = _t.zeros(0, dtype=_t.int64, device=device); secs = 0.0
+        summ = _t.zeros((0, 2 * D + 1), dtype=_t.float64, device=device)
     # timing: the job is as slow as its slowest rank
-    tt = torch.tensor([secs], dtype=torch.float64, device=device)
+    tt = _t.tensor([secs], dtype=_t.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     seconds = float(tt.item())
-    acc_all = _gather_rows(acc.reshape(-1, 1), counts, device)
-    steps_all = _gather_rows(steps.reshape(-1, 1), counts, device)
-    if gather == "samples":
-        payload = _gather_rows(smp, counts, device)
-    else:
-        g = _gather_rows(summ, counts, device)
-        payload = None if g is None else dict(mean=g[:, :D], var=g[:, D:2 * D], min_ess=g[:, 2 * D])
+    # the ONE exchange of the sharded path: counters and payload gathered to rank 0 from where the sampler left them
+    cnt_all = _gather_rows(_t.stack([acc, steps], dim=1), counts)
+    payload = _gather_rows(smp if gather == "samples" else summ, counts)
     if rank != 0:
         return None
-    info = dict(accepted=acc_all.ravel(), leapfrog_steps=steps_all.ravel(), world=world, counts=counts)
+    cnt_all = cnt_all.cpu().numpy()
+    if gather == "samples":
+        payload = payload.cpu().numpy()   # the drop-in contract returns host arrays; the transfer happens once, on rank 0
+    else:
+        g = payload.cpu().numpy()
+        payload = dict(mean=g[:, :D], var=g[:, D:2 * D], min_ess=g[:, 2 * D])
+    info = dict(accepted=cnt_all[:, 0], leapfrog_steps=cnt_all[:, 1], world=world, counts=counts)
     return payload, seconds, info

@@ -14,7 +14,7 @@ from riemannhamiltonianmontecarlo_amd import _capi, RMHMC
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "rmhmc.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(rmhmc_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(rmhmc_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_and_binding_agree():
@@ -77,16 +77,37 @@ def test_int8_metric_flag_helpers():
         with pytest.raises(ValueError):
             _capi.int8_metric_flags(bad)
     # auto rule: 6 slices where the path applies and the batch fills its 128-chain tiles, else the fp64 matrix cores
-    assert _capi.auto_metric_flags(64, 8192) == _capi.int8_metric_flags(6)
-    assert _capi.auto_metric_flags(256, 4096) == _capi.int8_metric_flags(6)
+    # (chosen by the shim => RMHMC_FLAG_INT8_CERTIFY: rmhmc_set_data may send data it cannot certify to 1e-9 to the fp64 kernels)
+    auto6 = _capi.int8_metric_flags(6) | _capi.FLAG_INT8_CERTIFY
+    assert _capi.FLAG_INT8_CERTIFY == 1 << 7
+    assert _capi.auto_metric_flags(64, 8192) == auto6
+    assert _capi.auto_metric_flags(256, 4096) == auto6
     assert _capi.auto_metric_flags(64, 100) == 0 and _capi.auto_metric_flags(8, 8192) == 0 and _capi.auto_metric_flags(300, 8192) == 0
     assert _capi.auto_metric_flags(64, 100, 5) == _capi.int8_metric_flags(5) and _capi.auto_metric_flags(64, 8192, 0) == 0
     # with the data size known the rule is the amount of work, chains * M * D^2 >= 1e9
-    assert _capi.auto_metric_flags(64, 128, M=10000) == _capi.int8_metric_flags(6)
-    assert _capi.auto_metric_flags(15, 8192, M=690) == _capi.int8_metric_flags(6)
+    assert _capi.auto_metric_flags(64, 128, M=10000) == auto6
+    assert _capi.auto_metric_flags(15, 8192, M=690) == auto6
     assert _capi.auto_metric_flags(25, 600, M=1000) == 0 and _capi.auto_metric_flags(15, 1, M=690) == 0
     # the flag values of the header and of the binding agree
     import os, re
     hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "rmhmc.h")).read()
     assert re.search(r"#define RMHMC_FLAG_INT8_METRIC \(1u << 5\)", hdr)
     assert re.search(r"#define RMHMC_FLAG_INT8_SLICES\(S\) \(\(\(uint32_t\)\(S\) & 7u\) << 12\)", hdr)
+
+
+def test_build_tracks_every_included_header():
+    """build() rebuilds librmhmc_hip.so when ANY header the translation unit pulls in changes (two hot-path headers
+    were missing from a hand-written list).  Every #include "..." reachable from rmhmc_hip.hip must be in hip_sources()."""
+    import __graft_entry__ as ge
+    srcs = {os.path.realpath(s) for s in ge.hip_sources()}
+    todo, seen = [os.path.join(ge.CSRC, "rmhmc_hip.hip")], set()
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), flags=re.M):
+            path = os.path.realpath(os.path.join(os.path.dirname(f), inc))
+            assert path in srcs, "%s (included by %s) is not tracked by build()" % (inc, os.path.basename(f))
+            todo.append(path)
+    assert len(seen) >= 6
