@@ -75,6 +75,11 @@ typedef struct rmhmc_ctx rmhmc_ctx;
 #define RMHMC_INT8_CERTIFY_TOL 1e-9
 #define RMHMC_FLAG_MMALA_FULL (1u << 6)  /* rmhmc_mmala_*: the full manifold MALA of BLR_mMALA.m (drift with the metric-
                                           derivative terms) instead of the simplified one of BLR_mMALA_Simp.m */
+#define RMHMC_FLAG_ESS_WRAP (1u << 9)     /* rmhmc_ess / rmhmc_sample_stats: autocorrelations exactly as the reference's PYTHON
+                                            tools.ac computes them, i.e. circular with period nFFT = nextpow2(S)+1
+                                            (tools.py:16-23: lag l also collects lag nFFT-l; differs from the linear ones
+                                            whenever S is close to a power of two).  Cleared (default): linear
+                                            autocovariances = the MATLAB original (ac.m:78, 2^(k+1)-point FFT, no wrap).  */
 #define RMHMC_FLAG_ORACLE_LITERAL (1u << 8) /* oracle only: form the DxDxD
                                                InvGdG tensor and use LU
                                                inv/solve like rmhmc.py:64-77  */
@@ -212,8 +217,8 @@ int rmhmc_hmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L,
  * Geyer initial-monotone-sequence ESS with the semantics of tools.CalculateESS(Samples, MaxLag = S-1)
  * (code/tools.py:32-74; authors_code/.../Results/CalculateESS.m), computed directly (autocovariances lag by
  * lag until the pair sum turns non-positive) instead of through an FFT of all lags: identical to the MATLAB
- * original (2^(k+1)-point FFT, ac.m:78) and to the Python translation wherever its 8193-point FFT does not
- * wrap around (lags < nFFT - S).                                                                      */
+ * original (2^(k+1)-point FFT, ac.m:78); with RMHMC_FLAG_ESS_WRAP identical to the Python translation, whose
+ * (nextpow2(S)+1)-point FFT wraps lag nFFT-l onto lag l (tools.py:23).                                  */
 
 /* samples[n*S*P] (host, chain-major, row s = sample s) -> ess_out[n*P].  n here is any number of sample
  * blocks (it need not equal the context's n_chains).  S <= 20000.                                      */
@@ -226,6 +231,18 @@ int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t 
                        uint64_t seed, int64_t chain_offset, const double *theta0, double *mean_out,
                        double *var_out, double *ess_out, int64_t *accept_out, int64_t *steps_out,
                        double *seconds_out);
+
+/* Progress reports of the bulk samplers (rmhmc_sample*, rmhmc_hmc_sample).  The reference prints the iteration count and the
+ * acceptance rate of the last window whenever IterationNum+1 is a multiple of 50 (rmhmc.py:38-45, hmc.py:32-38) and a banner
+ * when burn-in completes (rmhmc.py:194-196).  With a callback set, fn(RMHMC_EV_PROGRESS, m, accepted, user) is called from the
+ * calling thread each time EVERY chain has completed exactly m = first, first+every, first+2 every, ... transitions (accepted =
+ * accepted proposals summed over all chains so far), and fn(RMHMC_EV_BURNIN_DONE, burn_in+1, accepted, user) when the burn-in
+ * phase ends, just before the TimeTaken timer starts.  Samples do not depend on it.  fn = NULL switches the reports off.
+ * The oracle accepts the call and never reports.                                                                          */
+typedef void (*rmhmc_progress_fn)(int32_t event, int64_t iterations_done, int64_t accepted_total, void *user);
+#define RMHMC_EV_PROGRESS 0
+#define RMHMC_EV_BURNIN_DONE 1
+int rmhmc_set_progress(rmhmc_ctx *ctx, rmhmc_progress_fn fn, int64_t first, int64_t every, void *user);
 
 /* Certificate of the int8 metric path for the data of the last rmhmc_set_data: bound_out = worst-case error of any G_ab
  * relative to sqrt(G0_aa G0_bb), G0 = X'X/4 + I/alpha (0 when the path was not requested); active_out = 1 when the int8 kernels

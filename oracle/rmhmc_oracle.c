@@ -944,7 +944,8 @@ int rmhmc_hmc_sample(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t L,
 /* series x[s*stride], s < S.  Autocovariances are computed lag by lag (the FFT of tools.ac, tools.py:21-30,
  * yields the same sums for every lag it does not wrap); Gamma_j = rho_2j + rho_2j+1 (tools.py:46-50), running
  * minimum (:54-60), sum of the positive prefix (:62-67), floor at 1 (:70-71), ESS = S / MonoEst (:73). */
-static void ess_series(const double *x, int64_t S, int64_t stride, double *ess, double *mean_out, double *var_out) {
+/* nfft = 0: linear autocovariances (ac.m:78); nfft > 0: the circular ones of tools.py:21-30 with period nfft = nextpow2(S)+1 */
+static void ess_series(const double *x, int64_t S, int64_t stride, double *ess, double *mean_out, double *var_out, int64_t nfft) {
   double m = 0;
   for (int64_t s = 0; s < S; s++) m += x[s * stride];
   m /= (double)S;
@@ -959,6 +960,11 @@ static void ess_series(const double *x, int64_t S, int64_t stride, double *ess, 
     double a = 0, b = 0;
     for (int64_t s = 0; s + 2 * j < S; s++) a += xc[s] * xc[s + 2 * j];
     for (int64_t s = 0; s + 2 * j + 1 < S; s++) b += xc[s] * xc[s + 2 * j + 1];
+    if (nfft > 0) {
+      const int64_t w0 = nfft - 2 * j, w1 = nfft - 2 * j - 1;
+      if (j > 0) for (int64_t s = 0; s + w0 < S; s++) a += xc[s] * xc[s + w0];
+      for (int64_t s = 0; s + w1 < S; s++) b += xc[s] * xc[s + w1];
+    }
     double g = (a + b) / c0;
     if (g > prev) g = prev;
     if (!(g > 0)) break;
@@ -970,10 +976,18 @@ static void ess_series(const double *x, int64_t S, int64_t stride, double *ess, 
   free(xc);
 }
 
+static int64_t ess_nfft(const rmhmc_ctx *ctx, int64_t S) {
+  if (!(ctx->flags & RMHMC_FLAG_ESS_WRAP)) return 0;
+  int64_t n = 1;
+  while (n < S) n *= 2; /* tools.py:16-19 */
+  return n + 1;         /* tools.py:23 */
+}
+
 int rmhmc_ess(rmhmc_ctx *ctx, const double *samples, int64_t n, int64_t S, int32_t P, double *ess_out) {
   if (!ctx || !samples || !ess_out || n < 1 || S < 2 || P < 1) return fail(ctx, RMHMC_ERR_INVALID, "ess: bad argument");
+  const int64_t nfft = ess_nfft(ctx, S);
 #pragma omp parallel for schedule(dynamic)
-  for (int64_t i = 0; i < n * P; i++) ess_series(&samples[(i / P) * S * P + (i % P)], S, P, &ess_out[i], NULL, NULL);
+  for (int64_t i = 0; i < n * P; i++) ess_series(&samples[(i / P) * S * P + (i % P)], S, P, &ess_out[i], NULL, NULL, nfft);
   return RMHMC_OK;
 }
 
@@ -990,7 +1004,7 @@ int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t 
 #pragma omp parallel for schedule(dynamic)
     for (int64_t i = 0; i < ctx->n * D; i++) {
       double e, m, v;
-      if (S >= 2) ess_series(&smp[(i / D) * S * D + (i % D)], S, D, &e, &m, &v);
+      if (S >= 2) ess_series(&smp[(i / D) * S * D + (i % D)], S, D, &e, &m, &v, ess_nfft(ctx, S));
       else { m = smp[i]; v = 0; e = NAN; }
       if (ess_out) ess_out[i] = e;
       if (mean_out) mean_out[i] = m;
@@ -1149,4 +1163,9 @@ int rmhmc_int8_certificate(rmhmc_ctx *ctx, double *bound_out, int32_t *active_ou
   if (bound_out) *bound_out = 0.0;   /* the oracle is float64 throughout */
   if (active_out) *active_out = 0;
   return RMHMC_OK;
+}
+
+int rmhmc_set_progress(rmhmc_ctx *ctx, rmhmc_progress_fn fn, int64_t first, int64_t every, void *user) {
+  (void)fn; (void)first; (void)every; (void)user;   /* the oracle runs its chains to the end in parallel loops and never reports */
+  return ctx ? RMHMC_OK : RMHMC_ERR_INVALID;
 }

@@ -6,6 +6,6 @@ Host side of the C-ABI in include/rmhmc.h; mirrors the reference's
 from .rmhmc import RMHMC  # noqa: F401
 from .hmc import HMC  # noqa: F401
 from .mmala import mMALA  # noqa: F401
-from . import tools, data  # noqa: F401
+from . import tools, data, experiment  # noqa: F401
 
-__all__ = ["RMHMC", "HMC", "mMALA", "tools", "data"]
+__all__ = ["RMHMC", "HMC", "mMALA", "tools", "data", "experiment"]

@@ -18,6 +18,7 @@ FLAG_FP32_METRIC = 1 << 4
 FLAG_INT8_METRIC = 1 << 5
 FLAG_MMALA_FULL = 1 << 6
 FLAG_INT8_CERTIFY = 1 << 7
+FLAG_ESS_WRAP = 1 << 9      # ESS with the reference Python's wrapped FFT length (tools.py:23); default = MATLAB (no wrap)
 INT8_CERTIFY_TOL = 1e-9
 
 
@@ -53,6 +54,9 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int64, C.c_int64, C.c_void_p)
+EV_PROGRESS, EV_BURNIN_DONE = 0, 1
+
 # every symbol include/rmhmc.h declares, with its signature
 SIGNATURES = {
     "rmhmc_version": (C.c_char_p, []),
@@ -75,6 +79,7 @@ SIGNATURES = {
     "rmhmc_chains_restore": (C.c_int, [C.c_void_p, _lp, _lp]),
     "rmhmc_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _lp]),
     "rmhmc_int8_certificate": (C.c_int, [C.c_void_p, _dp, _ip]),
+    "rmhmc_set_progress": (C.c_int, [C.c_void_p, PROGRESS_FN, C.c_int64, C.c_int64, C.c_void_p]),
     "rmhmc_ess": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64, C.c_int32, _dp]),
     "rmhmc_sample_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                      _dp, _dp, _dp, _dp, _lp, _lp, _dp]),
@@ -349,6 +354,16 @@ class Context:
         it = np.ascontiguousarray(iters, dtype=np.int64).reshape(self.n)
         acc = np.ascontiguousarray(accepted, dtype=np.int64).reshape(self.n)
         self._ck(self.lib.rmhmc_chains_restore(self._h, _ptr(it, _lp), _ptr(acc, _lp)))
+
+    def set_progress(self, fn, first=49, every=50):
+        """fn(event, iterations_done, accepted_total) or None.  The defaults are the reference's schedule: a report whenever
+        IterationNum+1 is a multiple of 50, i.e. after 49, 99, ... completed transitions (rmhmc.py:38)."""
+        if fn is None:
+            self._progress_cb = PROGRESS_FN(0)
+            self._ck(self.lib.rmhmc_set_progress(self._h, self._progress_cb, 1, 1, None))
+            return
+        self._progress_cb = PROGRESS_FN(lambda ev, it, acc, user: fn(int(ev), int(it), int(acc)))   # kept alive with the context
+        self._ck(self.lib.rmhmc_set_progress(self._h, self._progress_cb, int(first), int(every), None))
 
     def int8_certificate(self):
         """(bound, active): worst-case error bound of the int8 metric path for the current data, and whether the int8 kernels are in use"""

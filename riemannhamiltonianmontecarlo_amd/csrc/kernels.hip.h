@@ -109,6 +109,12 @@ struct VSlice {
   int8_t* Vs;
   int* vbad;   // raised when a v is not in [0, 1/4] (non-finite: diverged chain); cleared by the host before the pass
   int nks, nCp, S;
+  // Per-chain exponent of the v grid.  The grid 2^-8S is absolute; a chain saturated on EVERY data row (all |x_n.w| large, which needs an
+  // intercept-like column bounded away from 0) would keep only its last byte.  From the column statistics cmin[d] = min_n |x_nd|,
+  // cmax[d] = max_n |x_nd|:  |x_n.w| >= max_d |w_d| (cmin_d + cmax_d) - sum_d |w_d| cmax_d =: f_lo for every row, and v <= e^-|f|, so
+  // v 2^vexp with vexp = floor(f_lo log2 e) - 3 (>= 0) still fits the grid; the assembly's epilogue divides by 2^vexp.
+  int* vexp;
+  const double *cmin, *cmax;
 };
 __device__ __forceinline__ unsigned transpose4x4_bytes(unsigned p, int rr) {
   const unsigned a = (unsigned)__shfl_xor((int)p, 16, 64);
@@ -134,6 +140,22 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
   double Wb[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
+  int vsh = 0;  // extra binary digits of the chain's v grid (see VSlice)
+  if (I8 && MODE != RP_G) {
+    double s1 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const double aw = fabs(Wb[kk]), cx = vs.cmax[4 * kk + rr];
+      s1 = fma(aw, cx, s1);
+      m1 = fmax(m1, aw * (vs.cmin[4 * kk + rr] + cx));
+    }
+    s1 = col4_sum(s1);
+    m1 = fmax(m1, __shfl_xor(m1, 16, 64));
+    m1 = fmax(m1, __shfl_xor(m1, 32, 64));
+    const double flo = m1 - s1;
+    if (flo > 4.0 && flo < 1e300) vsh = (int)fmin(900.0, floor(flo * 1.4426950408889634) - 3.0);
+    if (live && rr == 0 && split == 0) vs.vexp[cj] = vsh;
+  }
   const int nb16 = dd.Mp / 16;
   const int per = (nb16 + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(nb16, b0 + per);
@@ -185,7 +207,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
       }
     }
     if (I8 && MODE != RP_G) {
-      // byte k of Q[j] = digit j (least significant first) of rint(v 2^(8S)) for the lane's row rr + 4k; all lanes take part in
+      // byte k of Q[j] = digit j (least significant first) of rint(v 2^(8S + vexp)) for the lane's row rr + 4k; all lanes take part in
       // the shuffles, only live chains and stages inside the slice planes are stored
       unsigned Q[7];
 #pragma unroll
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
         if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
         // N = rint(x 2^(8S)) < 2^(8S-2) as two 32-bit words split at bit 24 (all in exact fp64 / int32 arithmetic: no 64-bit
         // integer emulation): three balanced digits from the low word, the carry and up to four more from the high word
-        const double y = rint(ldexp(x, 8 * vs.S));
+        const double y = rint(ldexp(x, 8 * vs.S + vsh));
         const double yh = floor(y * 5.9604644775390625e-08);  // 2^-24
         int lo = (int)(y - yh * 16777216.0), hi = (int)yh;
 #pragma unroll
@@ -1437,9 +1459,12 @@ __global__ __launch_bounds__(64) void k_mmala_end(int D, int DP, Chains ch, Iter
 // wavefront.  samples[(c*S + s)*P + d]; the centred series lives in LDS; autocovariances are evaluated lag by lag
 // (two per Geyer pair, tools.py:46-50) until the running-minimum pair sum (:54-60) turns non-positive, which is
 // where the reference's "sum of the positive Gammas" (:62-67) ends.  Also returns mean and population variance.
+// nfft = 0: linear autocovariances (the MATLAB original, ac.m:78: a 2^(k+1)-point FFT never wraps).  nfft > 0
+// (RMHMC_FLAG_ESS_WRAP): the reference's Python translation takes an FFT of length nFFT = nextpow2(S)+1 (tools.py:16-23), whose
+// circular autocorrelation at lag l is the linear one at l PLUS the linear one at nFFT - l; reproduced term by term.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_ess(const double* __restrict__ samples, long long S, int P, double* __restrict__ ess_out,
-                                            double* __restrict__ mean_out, double* __restrict__ var_out) {
+                                            double* __restrict__ mean_out, double* __restrict__ var_out, long long nfft) {
   extern __shared__ __attribute__((aligned(16))) double ess_x[];
   const long long idx = blockIdx.x;
   const long long c = idx / P;
@@ -1464,6 +1489,11 @@ __global__ __launch_bounds__(64) void k_ess(const double* __restrict__ samples, 
     double a = 0.0, b = 0.0;
     for (long long s = lane; s + l0 < S; s += 64) a = fma(ess_x[s], ess_x[s + l0], a);
     for (long long s = lane; s + l1 < S; s += 64) b = fma(ess_x[s], ess_x[s + l1], b);
+    if (nfft > 0) {  // wrapped partners of the two lags
+      const long long w0 = nfft - l0, w1 = nfft - l1;
+      if (l0 > 0) for (long long s = lane; s + w0 < S; s += 64) a = fma(ess_x[s], ess_x[s + w0], a);
+      for (long long s = lane; s + w1 < S; s += 64) b = fma(ess_x[s], ess_x[s + w1], b);
+    }
     double g = wave_sum(a + b) / c0;
     if (g > prev) g = prev;
     if (!(g > 0.0)) break;

@@ -9,7 +9,9 @@
 // error of 2e-12 on G at config 3, S = 6 1e-14 (the level of fp64 summation itself); see DESIGN.md and tools/i8_sweep.py.
 //
 // Error bound (what tests/test_gpu_int8_stress.py asserts and what RMHMC_FLAG_INT8_CERTIFY checks in rmhmc_set_data).
-//   Fixed-point grids: v in [0, 1/4] is rounded to a multiple of 2^-8S (ABSOLUTE grid, the same for every chain: |dv| <= 2^-(8S+1));
+//   Fixed-point grids: v in [0, 1/4] is rounded to a multiple of 2^-8S (absolute grid: |dv| <= 2^-(8S+1); refined to 2^-(8S+vexp_c) for a
+//   chain whose v is provably below 2^-(2+vexp_c) on every data row, see VSlice in kernels.hip.h: the bounds below then hold with an
+//   extra factor 2^-vexp_c, i.e. relative to that chain's own largest v);
 //   z_n,ab = x_na x_nb to a multiple of 2^(e_ab-8S+2), 2^e_ab > max_n |z_n,ab| (one exponent per column pair: |dz| <= 2^(e_ab-8S+1)).
 //   The integer GEMM is exact for the slice products it keeps (i + j < S); the dropped ones are at most
 //   (S-1) 2^14 256^(S-2) grid units per term.  Per data row n, with v <= 2^-2 and |z| < 2^e_ab:
@@ -22,10 +24,12 @@
 //   evaluated by rmhmc_set_data: 3e-12 for N(0,1) data at M = 10^4, S = 6; 1.4e-8 with one row 1000x the rest, which
 //   RMHMC_FLAG_INT8_CERTIFY sends to the fp64 kernels (tolerance 1e-9).  At a state whose mean curvature vbar = mean(v) is below 1/4
 //   the data part of G shrinks and the relative bound grows by 1/(4 vbar), until the prior floor: G >= I/alpha always, so
-//   |dG_ab| alpha <= S M 2^(e_ab-8S) alpha (7e-7 worst case / ~1e-10 typical at config 3) is the bound for a fully saturated
-//   chain (all |x_n.w| > 30: v below the absolute grid, G = I/alpha + O(1e-9)).
-//   Leverage pass: Q = G^-1 entries carry the CHAIN's exponent and Z the DATA ROW's, so h_n is accurate relative to
-//   max|G^-1| max_ab|x_na x_nb| for every (chain, row) pair: |dh_n| <= S NP 2^(eq_c + ez_n + 4 - 8S), NP = D(D+1)/2.
+//   |dG_ab| alpha <= S M 2^(e_ab-8S) alpha (7e-7 worst case at config 3) bounds any state; a chain saturated on every row (all
+//   |x_n.w| large: needs an intercept-like column) gets the refined grid above and stays at the accuracy of an unsaturated one.
+//   Leverage pass: the columns are equilibrated by exact powers of two first (x~_a = x_a 2^-cexp[a], |x~| < 1; Q~_ab = G^-1_ab
+//   2^(cexp[a]+cexp[b]), the inverse of the equilibrated metric), because x' G^-1 x is a sum of O(1) terms whose two factors vary by
+//   the SQUARE of the column scales in opposite directions.  Then Q~ carries the CHAIN's exponent and Z~ the DATA ROW's, so h_n is
+//   accurate relative to max|Q~| max_a|x~_na|^2 for every (chain, row): |dh_n| <= S NP 2^(eq_c + ez_n + 4 - 8S), NP = D(D+1)/2.
 //
 // Operand layout in HBM ("stage major": the tile one workgroup needs for one k-stage of 32 data rows is contiguous):
 //     Vs[S][nks][nCp][32]  int8     chains,       nCp = chains rounded up to 128
@@ -238,6 +242,8 @@ struct I8Pairs {
   const short* pb;
   const double* scale;  // 2^(e_p - 14): C[c][p] * scale = sum_n v_n z_np
   int NP, NPp;
+  const int* cexp;      // leverage pass: column a is used as x_a 2^-cexp[a] (|.| < 1) and G^-1_ab as G^-1_ab 2^(cexp[a]+cexp[b]): exact
+                        // power-of-two equilibration, so that x' G^-1 x is cut into bytes in units in which every column counts alike
 };
 
 // e_p: smallest exponent with max_n |x_na x_nb| < 2^e_p.  One workgroup per pair.
@@ -301,14 +307,36 @@ __global__ __launch_bounds__(256) void k_zsplit(const double* __restrict__ Xt, i
 template <int S>
 __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow, int Mp, int n_chains, const int* __restrict__ phase, int nks,
                                                 int nCp, int8_t* __restrict__ Vs, int* __restrict__ vbad, int D, int DP, double inv_alpha,
-                                                double* __restrict__ Gq) {
+                                                double* __restrict__ Gq, int* __restrict__ vexp) {
   __shared__ int sbad[8];
+  __shared__ unsigned long long smax[8];
   const int t = threadIdx.x;
   const int cl = (t >> 3) & 7, k4 = t & 7, ksl = t >> 6;
   const int c = blockIdx.x * 8 + cl;
   const bool live = c < n_chains && phase[min(c, n_chains - 1)] == 1;
-  if (t < 8) sbad[t] = 0;
+  if (t < 8) { sbad[t] = 0; smax[t] = 0ull; }
   __syncthreads();
+  // the chain's own exponent for the v grid (see VSlice in kernels.hip.h; here v is at hand, so the exact maximum is used):
+  // max_n v_n < 2^(-2 - vsh)
+  if (live) {
+    const double* v = vrow + (size_t)c * Mp;
+    double mx = 0.0;
+    for (int ks = ksl; ks < nks; ks += 4) {
+      const int n0 = 32 * ks + 4 * k4;
+      const double2 v01 = *(const double2*)(v + n0), v23 = *(const double2*)(v + n0 + 2);
+      const double m4 = fmax(fmax(v01.x, v01.y), fmax(v23.x, v23.y));
+      if (m4 > mx && m4 <= 0.25) mx = m4;  // (non-finite / out-of-range values are flagged below, not scaled for)
+    }
+    atomicMax(&smax[cl], (unsigned long long)__double_as_longlong(mx));  // v >= 0: the bit patterns order like the values
+  }
+  __syncthreads();
+  int vsh = 0;
+  {
+    const double mx = __longlong_as_double((long long)smax[cl]);
+    int e = 0;
+    if (mx > 0.0) { (void)frexp(mx, &e); vsh = min(900, max(0, -2 - e)); }
+    if (live && k4 == 0 && ksl == 0) vexp[c] = vsh;
+  }
   int bad = 0;
   if (live) {
     const double* v = vrow + (size_t)c * Mp;
@@ -324,7 +352,7 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
         double x = x4[k];
         if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
         int d[S];
-        split_digits<S>((long long)rint(ldexp(x, 8 * S)), d);
+        split_digits<S>((long long)rint(ldexp(x, 8 * S + vsh)), d);
 #pragma unroll
         for (int s = 0; s < S; ++s) w[s] |= (d[S - 1 - s] & 0xFF) << (8 * k);
       }
@@ -357,7 +385,7 @@ template <int S, int WN, int TN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
                                                           int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
                                                           const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
-                                                          size_t plane_stride) {
+                                                          size_t plane_stride, const int* __restrict__ vexp) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, pr.NPp / (32 * TN * WN), cb, pb)) return;
   // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow.
@@ -373,7 +401,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
     if (phase[c] != 1) return;
     const int a = pr.pa[p], b = pr.pb[p];  // b <= a: pairs run along the rows of the lower triangle
     double* gp = Gout + (size_t)c * DP * DP + a * DP + b;  // lower triangle only (contiguous in p): all the factor kernels read
-    double g = val * pr.scale[p];
+    double g = ldexp(val * pr.scale[p], -vexp[c]);  // (the chain's v grid is 2^-(8S + vexp))
     if (accumulate) g += *gp;
     else if (a == b && first) g += inv_alpha;
     if (vbad[c]) g = __builtin_nan("");
@@ -399,14 +427,14 @@ __global__ __launch_bounds__(256) void k_sum_planes(double* __restrict__ dst, co
 //     Qs[S][nkp][nCp][32]   Zt[S][nkp][NRp][32]     nkp = ceil(NP/32) stages of 32 pairs, NRp = data rows rounded up to the tile
 // The epilogue multiplies by c_n and writes R[chain][n] = c_n h_n; k_trvec contracts R with X on the fp64 matrix cores.
 // ---------------------------------------------------------------------------------------------
-// e'_n: smallest exponent with max_p |x_na x_nb| = (max_a |x_na|)^2 < 2^e'_n; zscale[n] = 2^e'_n
-__global__ __launch_bounds__(256) void k_zrowmax(const double* __restrict__ Xr, int M, int D, int DP, int NRp, int* __restrict__ ze,
-                                                 double* __restrict__ zscale) {
+// e'_n: smallest exponent with max_p |x~_na x~_nb| = (max_a |x~_na|)^2 < 2^e'_n, x~_na = x_na 2^-cexp[a]; zscale[n] = 2^e'_n
+__global__ __launch_bounds__(256) void k_zrowmax(const double* __restrict__ Xr, int M, int D, int DP, int NRp, const int* __restrict__ cexp,
+                                                 int* __restrict__ ze, double* __restrict__ zscale) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= NRp) return;
   double m = 0.0;
   if (n < M)
-    for (int d = 0; d < D; ++d) m = fmax(m, fabs(Xr[(size_t)n * DP + d]));
+    for (int d = 0; d < D; ++d) m = fmax(m, fabs(ldexp(Xr[(size_t)n * DP + d], -cexp[d])));
   m *= m;
   int e = 0;
   if (m > 0.0 && m < 1e300) (void)frexp(m, &e);
@@ -428,7 +456,11 @@ __global__ __launch_bounds__(256) void k_ztsplit(const double* __restrict__ Xr, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int p = 32 * kp + 4 * k4 + k;
-      const double z = p < pr.NP ? Xr[(size_t)n * DP + pr.pa[p]] * Xr[(size_t)n * DP + pr.pb[p]] : 0.0;
+      double z = 0.0;
+      if (p < pr.NP) {
+        const int a = pr.pa[p], b = pr.pb[p];
+        z = ldexp(Xr[(size_t)n * DP + a] * Xr[(size_t)n * DP + b], -(pr.cexp[a] + pr.cexp[b]));
+      }
       int d[S];
       split_digits<S>((long long)rint(ldexp(z, sh)), d);
 #pragma unroll
@@ -452,7 +484,8 @@ __global__ __launch_bounds__(256) void k_qsplit(const double* __restrict__ Ginv,
   double m = 0.0;
   bool bad = false;
   for (int p = t; p < pr.NP; p += 256) {
-    const double q = Gi[pr.pa[p] * DP + pr.pb[p]];
+    const int a = pr.pa[p], b = pr.pb[p];
+    const double q = ldexp(Gi[a * DP + b], pr.cexp[a] + pr.cexp[b]);
     bad |= !(fabs(q) < 1e300);
     m = fmax(m, fabs(q));
   }
@@ -483,7 +516,7 @@ __global__ __launch_bounds__(256) void k_qsplit(const double* __restrict__ Ginv,
       double q = 0.0;
       if (ok && p < pr.NP) {
         const int a = pr.pa[p], b = pr.pb[p];
-        q = Gi[a * DP + b] * (a == b ? 1.0 : 2.0);
+        q = ldexp(Gi[a * DP + b], pr.cexp[a] + pr.cexp[b] + (a == b ? 0 : 1));
       }
       int d[S];
       split_digits<S>((long long)rint(ldexp(q, shf)), d);

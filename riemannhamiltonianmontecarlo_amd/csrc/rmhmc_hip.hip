@@ -50,6 +50,7 @@ struct Group {
   double *Gpart = nullptr, *Rpart = nullptr;  // k-split planes of small batches ([ksplit][n][DP*DP], [ksplit][n][Mp])
   int ksplit_a = 1, ksplit_l = 1;
   int* vbad = nullptr;
+  int* vexp = nullptr;   // per-chain extra binary digits of the v grid (VSlice)
   int nCp = 0;
 };
 
@@ -87,6 +88,7 @@ struct rmhmc_ctx {
   int* d_ze = nullptr;
   int8_t* d_Zt = nullptr;   // leverage pass: x_a x_b sliced per data row, [S][nkp][NRp][32]
   int* d_zre = nullptr;
+  double *d_cmin = nullptr, *d_cmax = nullptr;  // min_n |x_nd|, max_n |x_nd| per column (VSlice)
   double* d_zscale = nullptr;
   int i8_nkp = 0, i8_NRp = 0;
   I8Pairs pairs{};
@@ -102,6 +104,10 @@ struct rmhmc_ctx {
   int *d_nsteps = nullptr, *d_dir = nullptr, *d_done = nullptr;
   long long* d_steps0 = nullptr;
   unsigned long long* d_miniter = nullptr;
+  // progress reports of the bulk samplers (rmhmc_set_progress)
+  rmhmc_progress_fn progress_fn = nullptr;
+  void* progress_user = nullptr;
+  long long progress_first = 0, progress_every = 0;
   // timing
   bool timing = false;
   std::map<std::string, std::vector<EvPair>> events;
@@ -203,7 +209,7 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
     if (ctx->i8 && MODE != RP_G) {  // int8 metric path: v goes out as byte slices (no fp64 row vector, no k_vsplit)
       (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
-      const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S};
+      const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
       NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
                                         out2, g.ch.gpart, g.ch.ljl_part, vs));
       return;
@@ -218,7 +224,7 @@ template <int S, int WN, int TN>
 void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part) {
   if (part == 0) {
     hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad,
-                       ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq);
+                       ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp);
     return;
   }
   const int nCB = g.nCp / I8_BM, nPB = ctx->pairs.NPp / (32 * TN * WN);
@@ -227,7 +233,7 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   if (g.ksplit_a > 1) {  // small batch: too few tiles to fill the chip, so the k range is cut into planes that are summed afterwards
     const size_t plane = (size_t)g.n * ctx->DP * ctx->DP;
     hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_a), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks,
-                       0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane);
+                       0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane, g.vexp);
     hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.Gq, g.Gpart, g.ksplit_a, plane, plane);
     return;
   }
@@ -235,7 +241,7 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   for (int ks0 = 0; ks0 < ctx->i8_nks; ks0 += ctx->i8_chunk) {
     const int nk = std::min(ctx->i8_chunk, ctx->i8_nks - ks0);
     hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp,
-                       ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0);
+                       ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0, g.vexp);
   }
 }
 // leverage pass of the int8 path: part 0 cuts G^-1 into slices, part 1 is the GEMM (R = c .* h into rv0, v is dead by then)
@@ -794,7 +800,10 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       HIPCK(hipMemcpyAsync(d_pa, pa.data(), NPp * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
       HIPCK(hipMemcpyAsync(d_pb, pb.data(), NPp * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
       RC(sync(ctx));
-      ctx->pairs = I8Pairs{d_pa, d_pb, d_scale, NP, NPp};
+      int* d_cexp;
+      RC(dalloc(ctx, &d_cexp, (size_t)ctx->DP));
+      RC(dalloc(ctx, &ctx->d_cmin, (size_t)ctx->DP)); RC(dalloc(ctx, &ctx->d_cmax, (size_t)ctx->DP));
+      ctx->pairs = I8Pairs{d_pa, d_pb, d_scale, NP, NPp, d_cexp};
       RC(dalloc(ctx, &ctx->d_Zs, (size_t)S * ctx->i8_nks * NPp * 32));
       ctx->i8_nkp = (NP + 31) / 32;
       ctx->i8_NRp = (ctx->Mp + ctx->i8_bn - 1) / ctx->i8_bn * ctx->i8_bn;
@@ -804,6 +813,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         g.nCp = (g.n + I8_BM - 1) / I8_BM * I8_BM;
         RC(dalloc(ctx, &g.Vs, (size_t)S * ctx->i8_nks * g.nCp * 32));
         RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
+        RC(dalloc(ctx, &g.vexp, (size_t)g.nCp));
         RC(dalloc(ctx, &g.Qs, (size_t)S * ctx->i8_nkp * g.nCp * 32));
         RC(dalloc(ctx, &g.qscale, (size_t)g.nCp));
         // small batches: cut the k range so that about 256 workgroups exist (at least 8 stages per piece, at most 16 pieces; only
@@ -937,13 +947,25 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
   HIPCK(hipMemcpyAsync((void*)ctx->dd.Xt, xt.data(), xt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCK(hipMemcpyAsync((void*)ctx->dd.t, tt.data(), tt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   if (ctx->i8_requested) {  // fixed operand of the int8 metric path: slices of x_a x_b for every column pair
+    std::vector<int> cexp(DP, 0);  // power-of-two column equilibration of the leverage pass: max_n |x_na| < 2^cexp[a]
+    std::vector<double> cmin(DP, 0.0), cmax(DP, 0.0);
+    for (size_t d = 0; d < D; ++d) {
+      double m = 0.0, lo = INFINITY;
+      for (size_t n = 0; n < M; ++n) { const double a = std::fabs(X[n * D + d]); m = std::max(m, a); lo = std::min(lo, a); }
+      if (m > 0.0 && m < 1e300) (void)std::frexp(m, &cexp[d]);
+      if (m < 1e300) { cmin[d] = lo; cmax[d] = m; }
+    }
+    HIPCK(hipMemcpyAsync((void*)ctx->pairs.cexp, cexp.data(), sizeof(int) * DP, hipMemcpyHostToDevice, ctx->stream));
+    HIPCK(hipMemcpyAsync(ctx->d_cmin, cmin.data(), sizeof(double) * DP, hipMemcpyHostToDevice, ctx->stream));
+    HIPCK(hipMemcpyAsync(ctx->d_cmax, cmax.data(), sizeof(double) * DP, hipMemcpyHostToDevice, ctx->stream));
+    RC(sync(ctx));  // (cexp is a local)
     hipLaunchKernelGGL(k_zmax, dim3((unsigned)ctx->pairs.NPp), dim3(256), 0, ctx->stream, ctx->dd.Xt, (int)M, (int)Mp, ctx->pairs, ctx->d_ze,
                        (double*)ctx->pairs.scale);
     const dim3 grid((unsigned)((ctx->i8_nks * 8 + 255) / 256), (unsigned)ctx->pairs.NPp);
     I8_SWITCH(ctx, hipLaunchKernelGGL((k_zsplit<S_>), grid, dim3(256), 0, ctx->stream, ctx->dd.Xt, (int)M, (int)Mp, ctx->pairs, ctx->d_ze,
                                       ctx->i8_nks, ctx->d_Zs); (void)WN_; (void)TN_);
     hipLaunchKernelGGL(k_zrowmax, dim3((unsigned)((ctx->i8_NRp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dd.Xr, (int)M, (int)D, (int)DP,
-                       ctx->i8_NRp, ctx->d_zre, ctx->d_zscale);
+                       ctx->i8_NRp, ctx->pairs.cexp, ctx->d_zre, ctx->d_zscale);
     const dim3 gridt((unsigned)(ctx->i8_NRp / 32), (unsigned)ctx->i8_nkp);
     I8_SWITCH(ctx, hipLaunchKernelGGL((k_ztsplit<S_>), gridt, dim3(256), 0, ctx->stream, ctx->dd.Xr, (int)M, (int)DP, ctx->pairs, ctx->d_zre,
                                       ctx->i8_nkp, ctx->i8_NRp, ctx->d_Zt); (void)WN_; (void)TN_);
@@ -1208,6 +1230,37 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
   return RMHMC_OK;
 }
 
+// rmhmc_set_progress: tell the caller that every chain has completed `iters` transitions
+static int report_progress(rmhmc_ctx* ctx, int event, long long iters) {
+  std::vector<long long> acc(ctx->n);
+  RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
+  RC(sync(ctx));
+  long long tot = 0;
+  for (long long a : acc) tot += a;
+  ctx->progress_fn(event, iters, tot, ctx->progress_user);
+  return RMHMC_OK;
+}
+// Every chain from exactly `from` to exactly ib.limit completed transitions.  With a progress callback the run is cut at the
+// milestones first, first+every, ...: all chains stop there (those that arrive first wait, as at the burn-in mark), the callback
+// gets the exact counters, and the run goes on; the results do not depend on it (the randomness is keyed by chain and iteration).
+static int run_phase(rmhmc_ctx* ctx, const IterBase& ib, long long from) {
+  if (ctx->progress_fn && ctx->progress_every > 0) {
+    long long m = ctx->progress_first;
+    if (from >= m) m += ((from - m) / ctx->progress_every + 1) * ctx->progress_every;
+    for (; m < ib.limit; m += ctx->progress_every) {
+      IterBase seg = ib;
+      seg.limit = m;
+      HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+      RC(run_until_done(ctx, seg, m - from));
+      RC(report_progress(ctx, RMHMC_EV_PROGRESS, m));
+      from = m;
+    }
+    HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+  }
+  if (ib.limit > from) RC(run_until_done(ctx, ib, ib.limit - from));
+  return RMHMC_OK;
+}
+
 // Runs the sampler; the saved states go to the device buffer d_samples ([n][S][D], caller-provided).  Per-chain counters are left
 // on the device: ch.accepted, and the post-burn-in leapfrog steps in d_steps0 (steps_done at the end minus at the burn-in mark).
 static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const double* theta0, double* d_samples, double* seconds_out) {
@@ -1216,14 +1269,15 @@ static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const do
   // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
   // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
   const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
-  RC(run_until_done(ctx, ipA, burn_in + 1));
+  RC(run_phase(ctx, ipA, 0));
   HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
   RC(sync(ctx));
+  if (ctx->progress_fn) RC(report_progress(ctx, RMHMC_EV_BURNIN_DONE, burn_in + 1));  // rmhmc.py:194-196: banner, then the timer starts
   const auto t0 = std::chrono::steady_clock::now();
   if (n_iter > burn_in + 1) {
     const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
-    RC(run_until_done(ctx, ipB, n_iter - burn_in - 1));
+    RC(run_phase(ctx, ipB, burn_in + 1));
   }
   RC(sync(ctx));
   if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1273,7 +1327,9 @@ int rmhmc_sample_dev(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L,
 static int launch_ess(rmhmc_ctx* ctx, const double* d_samples, long long nblocks, long long S, int P, double* d_ess, double* d_mean, double* d_var) {
   if (S < 2 || S > 20000) return fail(ctx, RMHMC_ERR_UNSUPPORTED, "ess: 2 <= S <= 20000 samples per chain (the centred series is held in LDS)");
   HIPCK(hipFuncSetAttribute((const void*)k_ess, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));  // per device: set where it is used
-  hipLaunchKernelGGL(k_ess, dim3((unsigned)(nblocks * P)), dim3(64), (size_t)S * sizeof(double), ctx->stream, d_samples, S, P, d_ess, d_mean, d_var);
+  long long nfft = 0;
+  if (ctx->flags & RMHMC_FLAG_ESS_WRAP) { nfft = 1; while (nfft < S) nfft *= 2; nfft += 1; }  // tools.py:16-23
+  hipLaunchKernelGGL(k_ess, dim3((unsigned)(nblocks * P)), dim3(64), (size_t)S * sizeof(double), ctx->stream, d_samples, S, P, d_ess, d_mean, d_var, nfft);
   return RMHMC_OK;
 }
 
@@ -1406,14 +1462,15 @@ int rmhmc_hmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L,
   int rc = [&]() -> int {
     RC(hmc_init_chains(ctx, theta0));
     const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
-    RC(run_until_done(ctx, ipA, burn_in + 1));
+    RC(run_phase(ctx, ipA, 0));
     HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
     RC(sync(ctx));
+    if (ctx->progress_fn) RC(report_progress(ctx, RMHMC_EV_BURNIN_DONE, burn_in + 1));  // hmc.py:92-94
     const auto t0 = std::chrono::steady_clock::now();
     if (n_iter > burn_in + 1) {
       const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
-      RC(run_until_done(ctx, ipB, n_iter - burn_in - 1));
+      RC(run_phase(ctx, ipB, burn_in + 1));
     }
     RC(sync(ctx));
     if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1567,6 +1624,12 @@ int rmhmc_chains_restore(rmhmc_ctx* ctx, const int64_t* iters, const int64_t* ac
   RC(upload(ctx, ctx->ch.iter, (const long long*)iters, ctx->n));
   RC(upload(ctx, ctx->ch.accepted, (const long long*)accepted, ctx->n));
   return sync(ctx);
+}
+
+int rmhmc_set_progress(rmhmc_ctx* ctx, rmhmc_progress_fn fn, int64_t first, int64_t every, void* user) {
+  if (!ctx || (fn && (first < 1 || every < 1))) return fail(ctx, RMHMC_ERR_INVALID, "set_progress: first >= 1 and every >= 1 required");
+  ctx->progress_fn = fn; ctx->progress_first = first; ctx->progress_every = every; ctx->progress_user = user;
+  return RMHMC_OK;
 }
 
 int rmhmc_int8_certificate(rmhmc_ctx* ctx, double* bound_out, int32_t* active_out) {

@@ -29,11 +29,12 @@ def HMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=100, StepSi
     lib = _lib if _lib is not None else _capi.load_hip_library()
     with lib.context(N, D, n_chains, flags=0, device=device) as ctx:
         ctx.set_data(XX, t, alpha)
+        if verbose:  # the reference's stdout, hmc.py:85-89,92-94
+            from .rmhmc import progress_printer
+            ctx.set_progress(progress_printer(n_chains, hmc_burn_in=BurnIn), first=1, every=50)
         samples, acc, steps, seconds = ctx.hmc_sample(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, seed=seed,
                                                       chain_offset=chain_offset, theta0=theta0)
     if verbose:
-        print('Acceptance: {}'.format(float(acc.sum()) / (NumOfIterations * n_chains)))
-        print('Burn-in complete, now drawing posterior samples.')
         print('Time drawing posterior: {}'.format(seconds))
     wSaved = samples[0] if n_chains == 1 else samples
     if return_info:

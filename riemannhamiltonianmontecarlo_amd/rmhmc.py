@@ -34,6 +34,25 @@ import numpy as np
 from . import _capi
 
 
+def progress_printer(n_chains, hmc_burn_in=None):
+    """The reference's stdout, driven by rmhmc_set_progress.  rmhmc.py:38-45,195: at the top of every iteration whose number+1 is a
+    multiple of 50 - i.e. after 49, 99, ... completed transitions - the text '<number+1> iterations completed.' and the acceptance
+    rate of the window since the last report (the first window holds 49 proposals), plus the burn-in banner.  hmc.py:85-89,92-94
+    (hmc_burn_in given): after iterations 0, 50, 100, ... up to BurnIn, '<number> iterations completed.' and the window's rate."""
+    last = {"it": 0, "acc": 0}
+
+    def report(event, iters, accepted):
+        if event == _capi.EV_BURNIN_DONE:
+            print('Burn-in complete, now drawing posterior samples.')
+            return
+        if hmc_burn_in is not None and iters - 1 > hmc_burn_in:
+            return
+        print('{} iterations completed.'.format(iters + 1 if hmc_burn_in is None else iters - 1))
+        print('Acceptance: {}'.format((accepted - last["acc"]) / float((iters - last["it"]) * n_chains)))
+        last["it"], last["acc"] = iters, accepted
+    return report
+
+
 def RMHMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=6, StepSize=0.5, NumOfNewtonSteps=4, *,
           n_chains=1, seed=None, compat=True, theta0=None, alpha=100.0, device=0, chain_offset=0, verbose=True,
           return_info=False, int8_slices=None, _lib=None):
@@ -54,13 +73,12 @@ def RMHMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=6, StepSi
     flags = (_capi.COMPAT if compat else 0) | _capi.auto_metric_flags(D, n_chains, int8_slices, M=N)
     with lib.context(N, D, n_chains, flags=flags, device=device) as ctx:
         ctx.set_data(XX, t, alpha)
+        if verbose:
+            ctx.set_progress(progress_printer(n_chains))
         samples, acc, steps, seconds = ctx.sample(NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize,
                                                   NumOfNewtonSteps, seed=seed, chain_offset=chain_offset,
                                                   theta0=theta0)
     if verbose:
-        print('{} iterations completed.'.format(NumOfIterations))
-        print('Acceptance: {}'.format(float(acc.sum()) / (NumOfIterations * n_chains)))
-        print('Burn-in complete, now drawing posterior samples.')
         print('Time drawing posterior: {}'.format(seconds))
     wSaved = samples[0] if n_chains == 1 else samples
     if return_info:

@@ -39,14 +39,14 @@ def hip():
     return _capi.load_hip_library()
 
 
-TAPES = ["pima", "australian", "german", "heart", "syn_m1000_d8", "syn_m50_d5_L1", "syn_m300_d20", "syn_m203_d33",
+TAPES = ["pima", "australian", "german", "heart", "ripley", "syn_m1000_d8", "syn_m50_d5_L1", "syn_m300_d20", "syn_m203_d33",
          "syn_m10000_d64_L1", "guard_w"]
 
 
 def load_tape(name):
     """Returns (XX, t, tape dict) for a golden transition tape captured from the reference."""
     g = dict(np.load(os.path.join(GOLDEN, "tape_%s.npz" % name)))
-    if name in ("pima", "australian", "german", "heart"):
+    if name in ("pima", "australian", "german", "heart", "ripley"):   # (ripley: the authors' cubic basis, D = 7)
         d = np.load(os.path.join(GOLDEN, "data_%s.npz" % name))
         XX, t = d["XX"], d["t"]
     else:

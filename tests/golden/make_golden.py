@@ -9,6 +9,7 @@ that the oracle (oracle/rmhmc_oracle.c) and the HIP library can replay exactly
 the same transitions.  Output: small ``.npz`` files next to this script.
 
     python tests/golden/make_golden.py            # regenerate everything
+    python tests/golden/make_golden.py ripley loader ess4096     # only the named groups (base, ripley, loader, ess4096)
 
 The fixtures hold data only (inputs, random draws, expected outputs); no
 reference source text is stored.
@@ -226,8 +227,63 @@ def save(name, **arrs):
     print("wrote %-40s %7.1f KB" % (os.path.basename(path), os.path.getsize(path) / 1024))
 
 
+def loader_fixture():
+    """Pin load_csv_dataset (riemannhamiltonianmontecarlo_amd/data.py) to the reference driver's own preprocessing: the block
+    main.py:19-41 (dataset_name .. XX = np.hstack) is EXECUTED from the reference file, unmodified apart from the dataset name, with
+    cwd = code/ as the script expects, for the two data sets it can select ('australian', 'heart': main.py:22,28).  Stored: the raw
+    CSV values and the (XX, t) the reference's lines produced."""
+    src = open(os.path.join(REF, "main.py")).read().splitlines()
+    assert src[17].strip() == "if __name__ == '__main__':" and src[18].strip().startswith("#%% Load and preprocess data"), src[17:19]
+    assert src[40].strip() == "XX = np.hstack((XX, X))", src[40]
+    block = "\n".join(line[4:] for line in src[19:41])          # lines 20-41, one indent level removed
+    out = {}
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        for ds in ("australian", "heart"):
+            code = block.replace("dataset_name = 'australian'", "dataset_name = %r" % ds)
+            assert code.count("dataset_name = %r" % ds) == 1
+            env = {"np": np}
+            exec(compile(code, "main.py[20:41]", "exec"), env)
+            out[ds + "_raw"] = np.loadtxt(os.path.join(REF, "data", ds + ".csv"), delimiter=",")
+            out[ds + "_XX"] = np.asarray(env["XX"], dtype=np.float64)
+            out[ds + "_t"] = np.asarray(env["t"], dtype=np.float64)
+    finally:
+        os.chdir(cwd)
+    save("loader_main_py", **out)
+
+
+def ripley_tape():
+    """RMHMC transitions of the reference on Ripley's data with the authors' cubic basis [1, X, X^2, X^3] (D = 7,
+    authors_code/Bayes_Log_Reg/MCMC/BLR_RMHMC.m:151-173): the Python reference is fed that XX (its main.py cannot select ripley)."""
+    XX, t = load_csv_dataset(os.path.join(REF, "data", "ripley.csv"), polynomial_order=3)
+    save("tape_ripley", **capture(XX, t, 12, 40))
+
+
+def ess_4096_fixture():
+    """tools.CalculateESS / tools.ac at S = 4096, a power of two: nFFT = nextpow2(S)+1 = 4097 (tools.py:23), so the circular
+    autocorrelation wraps from lag 1 on - the case where the reference's Python FFT length and the MATLAB one (ac.m:78) differ most."""
+    rs = np.random.RandomState(321)
+    S, P = 4096, 2
+    x = np.zeros((S, P)); rho = np.array([0.5, 0.97]); e = rs.randn(S, P)
+    for i in range(1, S):
+        x[i] = rho * x[i - 1] + e[i]
+    ess = ref_tools.CalculateESS(x, S - 1)
+    acf = np.stack([ref_tools.ac(x[:, j], 64) for j in range(P)], axis=1)
+    save("ess_s4096", samples=x.astype(np.float64), ess=ess.ravel(), acf64=acf, maxlag=np.int64(S - 1))
+
+
 def main():
     _check_lines()
+    groups = set(sys.argv[1:]) or {"base", "ripley", "loader", "ess4096"}
+    if "ripley" in groups:
+        ripley_tape()
+    if "loader" in groups:
+        loader_fixture()
+    if "ess4096" in groups:
+        ess_4096_fixture()
+    if "base" not in groups:
+        return
     # --- bundled datasets (main.py:20-41 preprocessing), stored as data fixtures ------------------
     for ds in ("pima", "australian", "german", "heart"):
         XX, t = load_csv_dataset(os.path.join(REF, "data", ds + ".csv"))

@@ -35,6 +35,16 @@ def _both(hip, oracle, XX, t, n, fn, flags):
     return out
 
 
+def _nan_rel(a, b):
+    """rel_err over the finite entries; non-finite entries (a trajectory that diverges does so in the oracle too) must coincide"""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    assert np.array_equal(fa, fb), "non-finite entries differ"
+    if not fb.any():
+        return 0.0
+    return float(np.max(np.abs(a[fb] - b[fb])) / max(np.max(np.abs(b[fb])), 1e-300))
+
+
 def _col_rel(a, b):
     """max over columns of (max_c |a - b|) / (max_c |b|): theta / p components live on the inverse column scales"""
     return float(np.max(np.abs(a - b).max(axis=0) / np.maximum(np.abs(b).max(axis=0), 1e-300)))
@@ -80,10 +90,10 @@ def test_saturated_chains(hip, oracle, f0):
     XX = np.hstack([np.ones((M, 1)), X0])
     rs = np.random.RandomState(int(f0))
     w = 0.02 * rs.randn(n, D) / np.sqrt(D); w[:, 0] = f0 * np.where(rs.rand(n) < 0.5, -1.0, 1.0)
-    p = 0.1 * rs.randn(n, D)
+    p = 0.01 * rs.randn(n, D)
 
     def fn(ctx):
-        return ctx.metric(w) + ctx.metric_terms(w, p) + ctx.leapfrog(w, p, 0.01, 1, 1, 4)
+        return ctx.metric(w) + ctx.metric_terms(w, p) + ctx.leapfrog(w, p, 1e-4, 1, 1, 4)
 
     (g, (bound, active)), (o, _) = _both(hip, oracle, XX, t, n, fn, _capi.int8_metric_flags(S))
     Gg, hg, gg, trg, qg, wg, pg, h1g, sg = g
@@ -93,8 +103,10 @@ def test_saturated_chains(hip, oracle, f0):
     assert (np.abs(Gg - Go) <= B[None]).all()
     worst = float((B * 100.0).max())                                           # relative to G >= I/alpha
     assert worst < 1e-6
+    assert np.isfinite(wo).all() and np.isfinite(po).all()
     for c in range(n):
-        assert rel_err(Gg[c], Go[c]) < min(worst, 1e-9), c                     # measured: far below the worst case
+        # the chain's own v grid (vexp, VSlice in kernels.hip.h) keeps a saturated chain at the accuracy of an ordinary one
+        assert rel_err(Gg[c], Go[c]) < 1e-12, c
         assert rel_err(wg[c], wo[c]) < 1e-9 and rel_err(pg[c], po[c]) < 1e-9, c
     assert np.abs(hg - ho).max() < 1e-9 * np.abs(ho).max()
     assert np.abs(trg - tro).max() <= 1e-9 * max(np.abs(tro).max(), 1e-30) + 1e-18
@@ -111,14 +123,14 @@ def test_outlier_row_is_sent_to_fp64_by_the_certificate(hip, oracle):
     w = 0.3 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
 
     def fn(ctx):
-        return ctx.metric(w) + ctx.leapfrog(w, p, 0.5, 1, 1, 4)
+        return ctx.metric(w) + ctx.leapfrog(w, p, 0.05, 1, 1, 4)
 
     auto = _capi.auto_metric_flags(D, 100000, M=M)                              # what RMHMC() / sample_sharded() pass for a big batch
     assert auto & _capi.FLAG_INT8_METRIC and auto & _capi.FLAG_INT8_CERTIFY
     (g, (bound, active)), (o, _) = _both(hip, oracle, XX, t, n, fn, auto)
     assert bound > _capi.INT8_CERTIFY_TOL and not active
     for a, b in zip(g, o):
-        assert rel_err(a, b) < 1e-11
+        assert _nan_rel(a, b) < 1e-11
     (g8, (bound8, active8)), _ = _both(hip, oracle, XX, t, n, fn, _capi.int8_metric_flags(S))
     assert active8 and bound8 == bound
     B = _bound_matrix(XX, S)

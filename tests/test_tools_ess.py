@@ -60,3 +60,28 @@ def test_oracle_direct_ess_matches_reference(oracle):
     assert np.array_equal(st["accepted"], acc) and np.array_equal(st["leapfrog_steps"], steps)
     ref = np.stack([tools.CalculateESS(s[i], 29, nfft="matlab").ravel() for i in range(3)])
     assert np.allclose(st["ess"], ref, rtol=1e-9)
+
+
+def test_python_fft_length_wraparound_is_reproduced(oracle):
+    """S = 4096, a power of two: the reference's nFFT = nextpow2(S)+1 = 4097 (tools.py:16-23) wraps lag nFFT-l onto lag l.  The host
+    restatement (nfft="python") and the C-ABI's direct evaluation with RMHMC_FLAG_ESS_WRAP reproduce the reference's outputs; the
+    default (linear autocovariances, the MATLAB original) is a different, documented estimator."""
+    g = np.load(os.path.join(GOLDEN, "ess_s4096.npz"))
+    x = g["samples"]
+    acf = np.stack([tools.ac(x[:, j], 64) for j in range(x.shape[1])], axis=1)
+    assert np.allclose(acf, g["acf64"], rtol=1e-10, atol=1e-13)
+    assert np.allclose(tools.CalculateESS(x, int(g["maxlag"])).ravel(), g["ess"], rtol=1e-9)
+    from riemannhamiltonianmontecarlo_amd import _capi
+    with oracle.context(10, 2, 1, flags=_capi.FLAG_ESS_WRAP) as ctx:
+        for name in ("ess_s4096", "ess_ar1", "ess_pima_chain"):
+            gg = np.load(os.path.join(GOLDEN, name + ".npz"))
+            assert np.allclose(ctx.ess(gg["samples"])[0], gg["ess"], rtol=1e-10), name
+    # a short series where the two FFT lengths visibly disagree: S = 9 -> nFFT = 17, lag l collects lag 17 - l
+    rs = np.random.RandomState(5)
+    y = np.cumsum(rs.randn(9, 3), axis=0)
+    with oracle.context(10, 2, 1, flags=_capi.FLAG_ESS_WRAP) as ctx:
+        wrapped = ctx.ess(y)[0]
+    with oracle.context(10, 2, 1, flags=0) as ctx:
+        linear = ctx.ess(y)[0]
+    assert np.allclose(wrapped, tools.CalculateESS(y, 8, nfft="python").ravel(), rtol=1e-10)
+    assert np.allclose(linear, tools.CalculateESS(y, 8, nfft="matlab").ravel(), rtol=1e-10)
