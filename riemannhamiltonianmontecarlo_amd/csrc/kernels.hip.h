@@ -127,7 +127,7 @@ template <int NB, int MODE, bool I8 = false>
 __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
                                                  double* __restrict__ out2, double* __restrict__ gpart,
-                                                 double* __restrict__ ljl_part, VSlice vs = VSlice{}) {
+                                                 double* __restrict__ ljl_part, VSlice vs = VSlice{}, d4* __restrict__ ctile = nullptr) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
   const int lane = threadIdx.x & 63;
@@ -156,6 +156,13 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
     if (flo > 4.0 && flo < 1e300) vsh = (int)fmin(900.0, floor(flo * 1.4426950408889634) - 3.0);
     if (live && rr == 0 && split == 0) vs.vexp[cj] = vsh;
   }
+  double vscale = 1.0, vmagic = 4503599627370496.0;  // 2^(8S + vexp) and 2^52 + B (fast slicing, S <= 6)
+  if (I8 && MODE != RP_G) {
+    vscale = ldexp(1.0, 8 * vs.S + vsh);
+    double bsum = 0.0;
+    for (int j = 0; j < vs.S && j < 6; ++j) bsum += ldexp(128.0, 8 * j);
+    vmagic += bsum;
+  }
   const int nb16 = dd.Mp / 16;
   const int per = (nb16 + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(nb16, b0 + per);
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
     double vv[4];
+    d4 cc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + rr + 4 * r;
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
       const double p = 1.0 / (1.0 + em);
       const double v = p * (1.0 - p);
       vv[r] = v;
+      cc[r] = v * (1.0 - 2.0 * p);
       const size_t o = (size_t)cj * dd.Mp + n;
       if (MODE == RP_V) {
         if (live && !I8) out0[o] = v;
@@ -206,12 +215,38 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
         for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rn, Gr[I], 0, 0, 0);
       }
     }
+    // c in the accumulator layout, for k_mompass<NB, 2> at the same position (same chain group / row block / lane mapping)
+    if (MODE == RP_F && ctile && live) ctile[((size_t)(c0 >> 4) * nb16 + b) * 64 + lane] = cc;
     if (I8 && MODE != RP_G) {
       // byte k of Q[j] = digit j (least significant first) of rint(v 2^(8S + vexp)) for the lane's row rr + 4k; all lanes take part in
       // the shuffles, only live chains and stages inside the slice planes are stored
       unsigned Q[7];
 #pragma unroll
       for (int j = 0; j < 7; ++j) Q[j] = 0u;
+      if (vs.S <= 6) {
+        // Fast path (at most 48 bits).  N = rint(x 2^k) = sum_j d_j 256^j with balanced digits d_j in [-128, 127]  <=>  N + B, B = sum_j<S
+        // 128 256^j, has the UNSIGNED bytes d_j + 128.  One fma puts N + B into the mantissa of a double in [2^52, 2^53) (round to
+        // nearest even at ulp 1: the same rounding as rint), so the digits are the mantissa bytes xor 0x80; a 4 x 6 byte transpose
+        // (v_perm_b32) turns the four rows' words into one dword per slice.
+        unsigned L[4], H[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double x = vv[r];
+          if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
+          const double z = fma(x, vscale, vmagic);
+          L[r] = (unsigned)__double2loint(z);
+          H[r] = (unsigned)__double2hiint(z);
+        }
+        const unsigned a = __builtin_amdgcn_perm(L[1], L[0], 0x05010400u), b2 = __builtin_amdgcn_perm(L[1], L[0], 0x07030602u);
+        const unsigned c = __builtin_amdgcn_perm(L[3], L[2], 0x05010400u), d2 = __builtin_amdgcn_perm(L[3], L[2], 0x07030602u);
+        Q[0] = __builtin_amdgcn_perm(c, a, 0x05040100u) ^ 0x80808080u;
+        Q[1] = __builtin_amdgcn_perm(c, a, 0x07060302u) ^ 0x80808080u;
+        Q[2] = __builtin_amdgcn_perm(d2, b2, 0x05040100u) ^ 0x80808080u;
+        Q[3] = __builtin_amdgcn_perm(d2, b2, 0x07060302u) ^ 0x80808080u;
+        const unsigned ah = __builtin_amdgcn_perm(H[1], H[0], 0x05010400u), ch = __builtin_amdgcn_perm(H[3], H[2], 0x05010400u);
+        Q[4] = __builtin_amdgcn_perm(ch, ah, 0x05040100u) ^ 0x80808080u;
+        Q[5] = __builtin_amdgcn_perm(ch, ah, 0x07060302u) ^ 0x80808080u;
+      } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double x = vv[r];
@@ -234,6 +269,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
           Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
           hi = (hi - bt) >> 8;
         }
+      }
       }
       const int ks = n0 >> 5;
       const bool st = live && ks < vs.nks;
@@ -422,9 +458,16 @@ __global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, 
 // Rows are split over blockIdx.y; partial sums go to qpart[split][chain][d] (summed, in fixed order,
 // by the momentum-update kernel: deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
-template <int NB>
+// c_n = v(1-2p) depends on the position only, and the fp64 matrix pipe is shared with the fp64 VALU (the exp / divide of c cost half
+// as much again as the pass's 48 MFMAs per tile), so c is computed once per position and kept in the accumulator layout of this
+// kernel ("tile native": ctile[(chain group * nb16 + row block) * 64 + lane] = the lane's four values, 2 KB contiguous per tile):
+//   CM 0  c from F = X W as above
+//   CM 1  the same, and the tile's values are stored                (first momentum fixed-point iteration of a step, rmhmc.py:102-110)
+//   CM 2  c loaded: no F product, no exp                             (the other K-1 iterations - same w -, and the pass of the point
+//         evaluation rmhmc.py:158-161, whose row pass k_rowpass<RP_F> has just stored c for the same w in the same layout)
+template <int NB, int CM>
 __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int nsplit, const double* __restrict__ wq,
-                                                 const double* __restrict__ uq, double* __restrict__ qpart) {
+                                                 const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
   const int lane = threadIdx.x & 63;
@@ -433,15 +476,16 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
   const int split = blockIdx.y;
   const int rr = lane >> 4, ci = lane & 15;
   const int cj = min(c0 + ci, n_chains - 1);
-  double Wb[KK], Ub[KK];
+  double Wb[CM == 2 ? 1 : KK], Ub[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
+    if (CM != 2) Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
     Ub[kk] = uq[(size_t)cj * DP + 4 * kk + rr];
   }
   const int nb16 = dd.Mp / 16;
   const int per = (nb16 + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(nb16, b0 + per);
+  d4* __restrict__ ct = ctile + (size_t)(c0 >> 4) * nb16 * 64 + lane;
   d4 Q[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Q[I] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -449,6 +493,8 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
   const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;   // A of Q  : X[n0+4r+rr][NB*ci+I]
   for (int b = b0; b < b1; ++b) {
     const int n0 = b * 16;
+    d4 cc;
+    if (CM == 2) cc = ct[(size_t)b * 64];
     double A[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + n0];
@@ -460,15 +506,21 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
     d4 F = (d4){0.0, 0.0, 0.0, 0.0}, S = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
+      if (CM != 2) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
       S = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Ub[kk], S, 0, 0, 0);
+    }
+    if (CM != 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double em = exp(-F[r]);
+        const double p = 1.0 / (1.0 + em);
+        cc[r] = p * (1.0 - p) * (1.0 - 2.0 * p);
+      }
+      if (CM == 1) ct[(size_t)b * 64] = cc;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double em = exp(-F[r]);
-      const double p = 1.0 / (1.0 + em);
-      const double cn = p * (1.0 - p) * (1.0 - 2.0 * p);
-      const double R = cn * S[r] * S[r];
+      const double R = cc[r] * S[r] * S[r];
 #pragma unroll
       for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], R, Q[I], 0, 0, 0);
     }

@@ -95,6 +95,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// I8_ABLATE (tools/i8_gemm_probe.hip only; the library never defines it): bit 0 no LDS-DMA loads, bit 1 no fragment reads (the
+// fragments of the first stage are kept), bit 2 no barriers.  Timing ablations: the results are meaningless.
+#ifndef I8_ABLATE
+#define I8_ABLATE 0
+#endif
 template <int S, int WN, int TN, int PIN, class Epilogue>
 __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks_total, int nks,
                                              int cb, int pb, int rows_real, int cols_real, Epilogue&& epi) {
@@ -126,6 +131,7 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
     lbase[k] = __builtin_amdgcn_readfirstlane((u & ~63) * 16);
   }
   auto gl = [&](int ks, int buf) {
+    if (I8_ABLATE & 1) return;
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -158,23 +164,26 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   if (nks > 1) { gl(1, 1); retire_older(); } else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   int cur = 0;
+  i4v fb[S][TN], fa[2][2];
   for (int ks = 0; ks < nks; ++ks) {
     const int nxt = cur == 2 ? 0 : cur + 1, wr = nxt == 2 ? 0 : nxt + 1;
     if (ks + 2 < nks) gl(ks + 2, wr);
-    const unsigned char* bc = lds + cur * STAGE;
+    const unsigned char* bc = lds + ((I8_ABLATE & 2) ? 0 : cur) * STAGE;
     if (WN != 4 || work) {
-    i4v fb[S][TN], fa[2][2];
+    const bool rd = !(I8_ABLATE & 2) || ks == 0;
     // issue order pinned (sched_barrier) so that the fragments of product group i+1 are in flight while group i is multiplied
     // and the compiler's counted lgkmcnt waits retire only what the next MFMA needs
+    if (rd) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) fa[0][a] = *(const i4v*)(bc + fragA + a * 32 * I8_ROWB);
 #pragma unroll
     for (int j = S - 1; j >= 0; --j)
 #pragma unroll
       for (int b = 0; b < TN; ++b) fb[j][b] = *(const i4v*)(bc + j * ROWS * I8_ROWB + fragB + b * 32 * I8_ROWB);
+    }
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      if (i + 1 < S) {
+      if (i + 1 < S && rd) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) fa[(i + 1) & 1][a] = *(const i4v*)(bc + (i + 1) * ROWS * I8_ROWB + fragA + a * 32 * I8_ROWB);
       }
@@ -192,7 +201,7 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
     }
     }
     if (ks + 2 < nks) retire_older(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if (!(I8_ABLATE & 4)) __builtin_amdgcn_s_barrier();
     cur = nxt;
   }
 #pragma unroll

@@ -51,6 +51,7 @@ struct Group {
   int ksplit_a = 1, ksplit_l = 1;
   int* vbad = nullptr;
   int* vexp = nullptr;   // per-chain extra binary digits of the v grid (VSlice)
+  d4* ctile = nullptr;   // c = v(1-2p) of trj.w in the tile layout of k_mompass, [ceil(n/16)][Mp/16][64] x 4 doubles
   int nCp = 0;
 };
 
@@ -80,6 +81,7 @@ struct rmhmc_ctx {
   size_t fused_lds = 0;
   bool medium = false;       // one-launch leapfrog step for small batches with 8 < D <= 32 (medium_step.hip.h)
   size_t medium_lds = 0;
+  bool ccache = true;        // c = v(1-2p) kept per position in the momentum pass's tile layout (RMHMC_CCACHE=0: recomputed every pass)
   bool hmc_traj = false;     // plain HMC in small batches: one launch per trajectory (k_hmc_traj)
   // int8 metric path (metric_i8.hip.h)
   bool i8 = false;
@@ -211,11 +213,11 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
       (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
       const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
       NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                        out2, g.ch.gpart, g.ch.ljl_part, vs));
+                                        out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile));
       return;
     }
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                      out2, g.ch.gpart, g.ch.ljl_part, VSlice{}));
+                                      out2, g.ch.gpart, g.ch.ljl_part, VSlice{}, g.ctile));
   });
 }
 
@@ -307,8 +309,9 @@ void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
   });
 }
 
-// q partials of u' dG/dw_d u for every chain (u = ch.uq, w as given); summed by k_mom_update / k_mom_final
-void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w) {
+// q partials of u' dG/dw_d u for every chain (u = ch.uq, w as given); summed by k_mom_update / k_mom_final.
+// cmode (generic path): 1 = first pass at this w, c is computed and kept; 2 = c of this w is at hand (k_mompass in kernels.hip.h)
+void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w, int cmode) {
   launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
     if (ctx->big) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
@@ -316,7 +319,12 @@ void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w) {
       return;
     }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
-    NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart));
+    if (!ctx->ccache) cmode = 0;
+    switch (cmode) {
+      case 1: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 1>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
+      case 2: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 2>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
+      default: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 0>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
+    }
   });
 }
 
@@ -407,7 +415,7 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, int
     ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
     return;
   }
-  ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
+  ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w, 2); });  // (the row pass above has just stored c for trj.w)
   ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
   ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
 }
@@ -448,7 +456,7 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
   for (int it = 0; it < K; ++it) {
     ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, it == 0 ? g.ch.p : g.ch.PM); });
-    ph.push_back([=](Group& g) { launch_mompass(ctx, g, g.ch.trj.w); });
+    ph.push_back([=](Group& g) { launch_mompass(ctx, g, g.ch.trj.w, it == 0 ? 1 : 2); });
     ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_mom_update, D, DP, g.ch, eps, it == K - 1 ? 1 : 0, g.nsplit); });
   }
   // implicit position step: K fixed-point iterations (rmhmc.py:113-123); the first one re-uses the
@@ -715,6 +723,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     ctx->NB = 4;
   }
   ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
+  if (const char* e = getenv("RMHMC_CCACHE")) ctx->ccache = atoi(e) != 0;
   int rc = RMHMC_OK;
   auto body = [&]() -> int {
     HIPCK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -768,6 +777,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       RC(dalloc(ctx, &g.ch.qpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.gpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.ljl_part, (size_t)g.n * g.nsplit));
+      if (!ctx->big && ctx->ccache) RC(dalloc(ctx, &g.ctile, (size_t)((g.n + 15) / 16) * (ctx->Mp / 16) * 64));
       if (ngroups > 1) {
         g.ring.resize(64);
         for (auto& e : g.ring) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

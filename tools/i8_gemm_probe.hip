@@ -81,6 +81,20 @@ int main(int argc, char** argv) {
       run_case<6, 4, 1, 1>(1920, 2080, 672, false, 10);
       return 0;
     }
+    if (S == 60) {  // the library configuration alone (built with -DI8_ABLATE=n for the ablations: see metric_i8.hip.h)
+      run_case<6, 4, 1, 1>(8192, 2080, 10000, false, 8);
+      run_case<5, 4, 1, 1>(8192, 2080, 10000, false, 8);
+      return 0;
+    }
+    if (S == 22) {  // 4 waves, 64x64 wave tile, one wave per SIMD (512 registers): a third fewer LDS fragment reads per MFMA
+      run_case<6, 2, 2, 1>(300, 300, 1000, true, 0);
+      run_case<6, 2, 2, 1>(8192, 2080, 10000, false, 5);
+      run_case<6, 2, 2, 0>(8192, 2080, 10000, false, 5);
+      run_case<6, 4, 1, 1>(8192, 2080, 10000, false, 5);
+      run_case<5, 2, 2, 1>(8192, 2080, 10000, false, 5);
+      run_case<5, 4, 1, 1>(8192, 2080, 10000, false, 5);
+      return 0;
+    }
     if (S == 5) run_case<5, 4, 1>(8192, 2080, 10000, false, 3);
     if (S == 6) run_case<6, 2, 1>(8192, 2080, 10000, false, 3);
     return 0;
