@@ -80,3 +80,72 @@ def test_device_resident_outputs_match_host_outputs(hip):
         for k in ("mean", "var", "ess", "accepted", "leapfrog_steps"):
             assert np.array_equal(d[k].cpu().numpy(), h[k], equal_nan=True), k
         assert np.allclose(h["mean"], s.mean(axis=1), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("shape", ["medium", "fused", "generic"])
+def test_progress_reports_follow_the_reference_schedule(hip, capsys, shape):
+    """rmhmc_set_progress: the reference prints '<k*50> iterations completed.' / 'Acceptance: ...' at the top of every iteration whose
+    number+1 is a multiple of 50 (rmhmc.py:38-45: 49 proposals in the first window, 50 afterwards) and the burn-in banner after iteration
+    BurnIn (:194-196).  The reports cut the run at those marks; the samples must not depend on them (one-launch, fused and generic
+    stepping paths)."""
+    from riemannhamiltonianmontecarlo_amd import RMHMC
+    M, D, n = {"medium": (400, 12, 1), "fused": (300, 6, 5), "generic": (500, 40, 3)}[shape]
+    XX, t = synthetic_logreg(M, D, 2)
+    events = []
+    with hip.context(M, D, n, flags=_capi.COMPAT) as ctx:
+        ctx.set_data(XX, t)
+        ctx.set_progress(lambda ev, it, acc: events.append((ev, it, acc)))
+        a = ctx.sample(230, 120, 6, 0.5, 4, seed=3)
+        ctx.set_progress(None)
+        b = ctx.sample(230, 120, 6, 0.5, 4, seed=3)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert [e[1] for e in events if e[0] == _capi.EV_PROGRESS] == [49, 99, 149, 199]
+    assert [e[1] for e in events if e[0] == _capi.EV_BURNIN_DONE] == [121]
+    assert [e[1] for e in events] == [49, 99, 121, 149, 199]                      # banner between the reports, where the reference prints it
+    accs = [e[2] for e in events]
+    assert accs == sorted(accs) and accs[-1] <= a[1].sum() <= 230 * n             # accepted-so-far is monotone and consistent with the total
+    if n == 1:
+        capsys.readouterr()
+        RMHMC(XX, t, NumOfIterations=230, BurnIn=120, seed=3)
+        out = capsys.readouterr().out.splitlines()
+        assert out[0] == "50 iterations completed." and out[1] == "Acceptance: %s" % (events[0][2] / 49.0)
+        assert out[2] == "100 iterations completed." and out[3] == "Acceptance: %s" % ((events[1][2] - events[0][2]) / 50.0)
+        assert out[4] == "Burn-in complete, now drawing posterior samples."
+        assert out[5] == "150 iterations completed." and out[-1].startswith("Time drawing posterior: ")
+
+
+_SHARDED_SCRIPT = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from riemannhamiltonianmontecarlo_amd import _capi, multi_gpu
+from riemannhamiltonianmontecarlo_amd.data import synthetic_logreg
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29647")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))            # RCCL
+XX, t = synthetic_logreg(600, 10, 4)
+smp, secs, info = multi_gpu.sample_sharded(XX, t, 37, 40, 15, seed=6, compat=False, gather="samples")
+summ, _, info2 = multi_gpu.sample_sharded(XX, t, 37, 40, 15, seed=6, compat=False, gather="summary")
+lib = _capi.load_hip_library()
+with lib.context(600, 10, 37, flags=0) as ctx:
+    ctx.set_data(XX, t)
+    ref, acc, steps, _ = ctx.sample(40, 15, seed=6)
+ok = bool(np.array_equal(smp, ref) and np.array_equal(info["accepted"], acc) and np.array_equal(info["leapfrog_steps"], steps)
+          and np.allclose(summ["mean"], ref.mean(axis=1), rtol=1e-12, atol=1e-14) and np.array_equal(info2["accepted"], acc))
+print(json.dumps({"ok": ok, "backend": dist.get_backend(), "world": dist.get_world_size(), "shape": list(smp.shape)}))
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_sampler_gathers_from_hbm_through_rccl(tmp_path):
+    """multi_gpu.sample_sharded with the nccl backend (= RCCL) on the one GPU of the box: the sampler's device-resident outputs go
+    through torch.distributed.gather as CUDA tensors and come out bit-equal to a direct rmhmc_sample call."""
+    script = tmp_path / "sharded.py"
+    script.write_text(_SHARDED_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out == {"ok": True, "backend": "nccl", "world": 1, "shape": [37, 25, 10]}

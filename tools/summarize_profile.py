@@ -64,7 +64,7 @@ for ctr, names in (("mfma", ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")), ("
         if ctr == "mfma" and "GRBM_GUI_ACTIVE" in vals and k in kernel_avg_ns:
             clk = vals["GRBM_GUI_ACTIVE"] / 8.0 / (kernel_avg_ns[k] * 1e-9)          # Hz (un-profiled duration of the stats pass)
             cyc = vals["GRBM_GUI_ACTIVE"] / 8.0
-            busy = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * 4.0 / (1024.0 * cyc) if cyc else 0.0
+            busy = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc) if cyc else 0.0   # 1024 SIMDs; as in profiles/r01_i8_gemm_probe.txt
             extra = "  clock %.2f GHz  MFMA busy %.1f %%" % (clk / 1e9, 100 * busy)
             vals["effective_clock_ghz"] = clk / 1e9; vals["mfma_busy_frac"] = busy
         lines.append("%-62s %s%s" % (k, "  ".join("%s=%.4g" % kv for kv in vals.items() if not kv[0].startswith(("eff", "mfma_b"))), extra))
