@@ -17,6 +17,20 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define RM_LD 66            // LDS leading dimension of the per-chain DxD matrix (even: 16-byte aligned rows for ds_read_b128, conflict free)
 #define RM_PI2 6.283185307179586476925286766559
+// Packed form of the same LDS image (PK = true in the routines below): only the lower BLOCK triangle of 16 x 16 blocks is kept - the
+// Cholesky / solve / inverse routines never touch a block above the diagonal -, row i of block row I = i >> 4 holding its 16 (I + 1)
+// columns with leading dimension 16 I + 18 (16-byte aligned, the same bank pattern as RM_LD).  21.5 KB instead of 33.8 KB per matrix:
+// seven chains per CU instead of four for the latency-bound per-chain kernels.  Reads past a row's end (lanes that run a loop whose
+// result they discard) stay inside the allocation thanks to the 64 doubles of slack.
+#define RM_PK_DOUBLES (2688 + 64)
+template <bool PK>
+__device__ __forceinline__ int rm_row(int i) {
+  if (!PK) return i * RM_LD;
+  const int I = i >> 4;
+  return (128 * I + 160) * I + (i & 15) * (16 * I + 18);
+}
+template <bool PK>
+__device__ __forceinline__ int rm_len(int i) { return PK ? 16 * ((i >> 4) + 1) : 64; }  // columns of row i that exist
 
 struct DevData {
   const double* Xr;
@@ -685,17 +699,18 @@ __device__ __forceinline__ int chol_lds(double* A, int D, int lane, double& rdia
 // matrix gets its rank-16 update A_IJ -= P_I P_J' on the fp64 matrix cores, operands straight from the LDS image (one ds_read
 // per 16-row panel tile and k-step serves as A of tile row I and as B of tile column I).  Three times fewer serial LDS round
 // trips than chol_lds at D = 64.  Rows / columns D..16*NB-1 are padded with the identity here.
-template <int NB>
+template <int NB, bool PK = false>
 __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& rdiag) {
   constexpr int DPc = 16 * NB;
   int bad = 0;
   rdiag = 1.0;
-  double* rowp = A + lane * RM_LD;
+  double* rowp = A + rm_row<PK>(lane);
+  const int rlen = min(DPc, rm_len<PK>(lane));  // (PK: the blocks above the diagonal do not exist, and are never read)
   if (D < DPc) {
     if (lane >= D && lane < DPc)
-      for (int m = 0; m < DPc; ++m) rowp[m] = (m == lane) ? 1.0 : 0.0;
+      for (int m = 0; m < rlen; ++m) rowp[m] = (m == lane) ? 1.0 : 0.0;
     else if (lane < D)
-      for (int m = D; m < DPc; ++m) rowp[m] = 0.0;
+      for (int m = D; m < rlen; ++m) rowp[m] = 0.0;
     __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
@@ -703,7 +718,7 @@ __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& 
     const int c0 = 16 * kb;
     for (int j = 0; j < 16; ++j) {
       const int jj = c0 + j;
-      const double s = neg_dot_lds(rowp + c0, A + jj * RM_LD + c0, j, rowp[jj]);  // meaningful for lanes jj..DPc-1
+      const double s = neg_dot_lds(rowp + c0, A + rm_row<PK>(jj) + c0, j, rowp[jj]);  // meaningful for lanes jj..DPc-1
       const double sjj = rdlane(s, jj);
       if (!(sjj > 0.0)) bad = 1;
       const double rinv = rsqrt(sjj);
@@ -723,7 +738,7 @@ __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& 
       for (int k0 = 0; k0 < 16; k0 += 4) {
         double op[NB];
 #pragma unroll
-        for (int I = kb + 1; I < NB; ++I) op[I] = A[(16 * I + ii) * RM_LD + c0 + k0 + kk];
+        for (int I = kb + 1; I < NB; ++I) op[I] = A[rm_row<PK>(16 * I + ii) + c0 + k0 + kk];
 #pragma unroll
         for (int I = kb + 1; I < NB; ++I)
 #pragma unroll
@@ -734,7 +749,7 @@ __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& 
 #pragma unroll
         for (int J = kb + 1; J <= I; ++J)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) A[(16 * I + kk + 4 * r) * RM_LD + 16 * J + ii] -= acc[I][J][r];
+          for (int r = 0; r < 4; ++r) A[rm_row<PK>(16 * I + kk + 4 * r) + 16 * J + ii] -= acc[I][J][r];
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -742,8 +757,9 @@ __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& 
   return bad;
 }
 // x = (L L')^-1 b ; lane i holds b_i on entry and x_i on return; rdiag as produced by chol_lds
+template <bool PK = false>
 __device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane, double b, double rdiag) {
-  const double* rowp = L + lane * RM_LD;
+  const double* rowp = L + rm_row<PK>(lane);
   int k = 0;
   for (; k + 4 <= D; k += 4) {  // forward, column oriented; the four multipliers are fetched up front
     const double2 l01 = lds2(rowp + k), l23 = lds2(rowp + k + 2);
@@ -762,7 +778,7 @@ __device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane
   }
   k = D - 1;
   for (; k >= 3; k -= 4) {  // backward with L'
-    const double lk[4] = {L[k * RM_LD + lane], L[(k - 1) * RM_LD + lane], L[(k - 2) * RM_LD + lane], L[(k - 3) * RM_LD + lane]};
+    const double lk[4] = {L[rm_row<PK>(k) + lane], L[rm_row<PK>(k - 1) + lane], L[rm_row<PK>(k - 2) + lane], L[rm_row<PK>(k - 3) + lane]};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double xk = rdlane(b, k - q) * rdlane(rdiag, k - q);
@@ -773,12 +789,13 @@ __device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane
   for (; k >= 0; --k) {
     const double xk = rdlane(b, k) * rdlane(rdiag, k);
     if (lane == k) b = xk;
-    else if (lane < k) b = fma(-L[k * RM_LD + lane], xk, b);
+    else if (lane < k) b = fma(-L[rm_row<PK>(k) + lane], xk, b);
   }
   return b;
 }
 
 // DxD matrix (row stride DP in HBM) -> LDS, eight row loads in flight
+template <bool PK = false>
 __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict__ G, int D, int DP, int lane) {
   const int l = lane < D ? lane : 0;
   int i = 0;
@@ -787,23 +804,25 @@ __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = G[(i + q) * DP + l];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) A[(i + q) * RM_LD + lane] = v[q];
+    for (int q = 0; q < 8; ++q)
+      if (lane < rm_len<PK>(i + q)) A[rm_row<PK>(i + q) + lane] = v[q];
   }
-  for (; i < D; ++i) A[i * RM_LD + lane] = G[i * DP + l];
+  for (; i < D; ++i)
+    if (lane < rm_len<PK>(i)) A[rm_row<PK>(i) + lane] = G[i * DP + l];
   __builtin_amdgcn_wave_barrier();
 }
 
 // position fixed point, first iterate (rmhmc.py:113-122 with FixedIter = 0): G(Pw^0) = G(w) is the
 // factor already stored in the trajectory record, so u = u0 and Pw^1 = w + tau*eps*u0.
 __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps) {
-  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
-  load_mat_lds(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
-  const double rdiag = (lane < D) ? 1.0 / A[lane * RM_LD + lane] : 1.0;
+  load_mat_lds<true>(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
+  const double rdiag = (lane < D) ? 1.0 / A[rm_row<true>(lane) + lane] : 1.0;
   const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
-  const double u0 = cholsolve_lds(A, D, lane, pb, rdiag);
+  const double u0 = cholsolve_lds<true>(A, D, lane, pb, rdiag);
   if (lane < D) {
     ch.u0[(size_t)c * DP + lane] = u0;
     ch.wq[(size_t)c * DP + lane] = ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * eps * u0;
@@ -813,15 +832,15 @@ __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, doub
 // position fixed point, iterate k>=1 (rmhmc.py:116-122): factor G(Pw^k), solve, update Pw.
 template <int NB>
 __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, double eps) {
-  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
-  load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
+  load_mat_lds<true>(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
   double rdiag;
-  const int bad = chol_lds_blk<NB>(A, D, lane, rdiag);
+  const int bad = chol_lds_blk<NB, true>(A, D, lane, rdiag);
   const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
-  const double u = cholsolve_lds(A, D, lane, pb, rdiag);
+  const double u = cholsolve_lds<true>(A, D, lane, pb, rdiag);
   if (lane < D)
     ch.wq[(size_t)c * DP + lane] =
         ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * (eps * 0.5) * (ch.u0[(size_t)c * DP + lane] + u);
@@ -857,29 +876,31 @@ __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int 
 // reads only columns > j of W and column j of L, which is overwritten afterwards; then G^-1 = W' W on the fp64 matrix cores with
 // the operands read straight from the LDS image (A[i][k] = W[m0+k][16I+i], B[k][j] = W[m0+k][16J+j]: one ds_read per 16-column
 // tile serves both), lower tiles only, written back into A.
-template <int NB>
+template <int NB, bool PK = false>
 __device__ __forceinline__ void spd_inverse_lds(double* A, int D, int lane, double rdiag) {
   constexpr int DPc = 16 * NB;
   // W = L^-1 in place.  Diagonal and the zero upper triangle / padding rows first, so that every lane runs the same loop.
   {
-    double* rowp = A + lane * RM_LD;
+    double* rowp = A + rm_row<PK>(lane);
+    const int rlen = min(DPc, rm_len<PK>(lane));
     if (lane < D) {
       rowp[lane] = rdiag;
-      for (int m = lane + 1; m < DPc; ++m) rowp[m] = 0.0;
+      for (int m = lane + 1; m < rlen; ++m) rowp[m] = 0.0;
     } else {
-      for (int m = 0; m < DPc; ++m) rowp[m] = 0.0;
+      for (int m = 0; m < rlen; ++m) rowp[m] = 0.0;
     }
     __builtin_amdgcn_wave_barrier();
+    const int mEnd = PK ? min(D, rlen) : D;  // (PK: W[lane][m] = 0 beyond the row's own blocks, which are not stored)
     for (int j = D - 2; j >= 0; --j) {
       double s0 = 0.0, s1 = 0.0;
       int m = j + 1;
-      if ((m & 1) && m < D) { s0 = fma(rowp[m], A[m * RM_LD + j], s0); ++m; }
-      for (; m + 4 <= D; m += 4) {
+      if ((m & 1) && m < mEnd) { s0 = fma(rowp[m], A[rm_row<PK>(m) + j], s0); ++m; }
+      for (; m + 4 <= mEnd; m += 4) {
         const double2 w01 = lds2(rowp + m), w23 = lds2(rowp + m + 2);
-        s0 = fma(w01.x, A[m * RM_LD + j], s0); s1 = fma(w01.y, A[(m + 1) * RM_LD + j], s1);
-        s0 = fma(w23.x, A[(m + 2) * RM_LD + j], s0); s1 = fma(w23.y, A[(m + 3) * RM_LD + j], s1);
+        s0 = fma(w01.x, A[rm_row<PK>(m) + j], s0); s1 = fma(w01.y, A[rm_row<PK>(m + 1) + j], s1);
+        s0 = fma(w23.x, A[rm_row<PK>(m + 2) + j], s0); s1 = fma(w23.y, A[rm_row<PK>(m + 3) + j], s1);
       }
-      for (; m < D; ++m) s0 = fma(rowp[m], A[m * RM_LD + j], s0);
+      for (; m < mEnd; ++m) s0 = fma(rowp[m], A[rm_row<PK>(m) + j], s0);
       const double rj = rdlane(rdiag, j);
       __builtin_amdgcn_wave_barrier();
       if (lane > j && lane < D) rowp[j] = -(s0 + s1) * rj;
@@ -896,7 +917,7 @@ __device__ __forceinline__ void spd_inverse_lds(double* A, int D, int lane, doub
     for (int m0 = 0; m0 < DPc; m0 += 4) {
       double op[NB];
 #pragma unroll
-      for (int I = 0; I < NB; ++I) op[I] = A[(m0 + kk) * RM_LD + 16 * I + ii];
+      for (int I = 0; I < NB; ++I) op[I] = A[rm_row<PK>(m0 + kk) + 16 * I + ii];  // (PK, rows above block row I: past the row's end, not used below)
       int q = 0;
 #pragma unroll
       for (int I = 0; I < NB; ++I)
@@ -916,7 +937,7 @@ __device__ __forceinline__ void spd_inverse_lds(double* A, int D, int lane, doub
 #pragma unroll
       for (int J = 0; J <= I; ++J) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A[(16 * I + (lane >> 4) + 4 * r) * RM_LD + 16 * J + (lane & 15)] = acc[q][r];
+        for (int r = 0; r < 4; ++r) A[rm_row<PK>(16 * I + (lane >> 4) + 4 * r) + 16 * J + (lane & 15)] = acc[q][r];
         ++q;
       }
   }
@@ -931,28 +952,28 @@ __device__ __forceinline__ void spd_inverse_lds(double* A, int D, int lane, doub
 // tiles only.  The product is exactly symmetric by construction.
 template <int NB>
 __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int nsplit) {
-  __shared__ __attribute__((aligned(16))) double A[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   constexpr int DPc = 16 * NB;
   const int D = dd.D, DP = dd.DP;
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
-  load_mat_lds(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
+  load_mat_lds<true>(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
   double rdiag;
-  const int bad = chol_lds_blk<NB>(A, D, lane, rdiag);
+  const int bad = chol_lds_blk<NB, true>(A, D, lane, rdiag);
   // half log det = sum log diag(L) = -sum log(1/L_jj)   (rmhmc.py:171,175)
   const double hld = -wave_sum((lane < D) ? log(rdiag) : 0.0);
   // store L (lower, zeros above)
   double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
   for (int i = 0; i < D; ++i)
-    if (lane < D) Lg[i * DP + lane] = (lane <= i) ? A[i * RM_LD + lane] : 0.0;
+    if (lane < D) Lg[i * DP + lane] = (lane <= i) ? A[rm_row<true>(i) + lane] : 0.0;
   __builtin_amdgcn_wave_barrier();
-  spd_inverse_lds<NB>(A, D, lane, rdiag);
+  spd_inverse_lds<NB, true>(A, D, lane, rdiag);
   double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
   const double pl = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
   double u = 0.0;
   for (int i = 0; i < D; ++i) {
-    const double gi = (lane <= i) ? A[i * RM_LD + lane] : A[min(lane, DPc - 1) * RM_LD + i];
+    const double gi = (lane <= i) ? A[rm_row<true>(i) + lane] : A[rm_row<true>(min(lane, DPc - 1)) + i];
     if (lane < D) Gi[i * DP + lane] = gi;
     u = fma((lane < D) ? gi : 0.0, rdlane(pl, i), u);  // u = G^-1 p
   }
@@ -1062,11 +1083,20 @@ __device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, 
     dst.tr[o + d] = src.tr[o + d];
   }
   const size_t m = (size_t)c * DP * DP;
-  for (int i = 0; i < D; ++i)
-    for (int d = lane; d < D; d += 64) {
+  for (int d = lane; d < D; d += 64) {
+    int i = 0;
+    for (; i + 8 <= D; i += 8) {  // eight rows of both matrices in flight (the copy is latency bound: one wavefront per chain)
+      double a[8], b[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a[q] = src.L[m + (i + q) * DP + d]; b[q] = src.Ginv[m + (i + q) * DP + d]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { dst.L[m + (i + q) * DP + d] = a[q]; dst.Ginv[m + (i + q) * DP + d] = b[q]; }
+    }
+    for (; i < D; ++i) {
       dst.L[m + i * DP + d] = src.L[m + i * DP + d];
       dst.Ginv[m + i * DP + d] = src.Ginv[m + i * DP + d];
     }
+  }
   if (lane == 0) {
     dst.ljl[c] = src.ljl[c];
     dst.hld[c] = src.hld[c];
