@@ -322,9 +322,11 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
 // bytes per step) and the same registers serve as A (scaled by v_n) and B operands.
 // Only tiles I<=J are computed (G is symmetric): NB(NB+1)/2 MFMAs per 4 data rows.
 // ---------------------------------------------------------------------------------------------
+// gridDim.y > 1 (small batches: fewer wavefronts than SIMDs, each walking all M rows): the rows are cut into gridDim.y ranges, range
+// y writes plane y (plane_stride apart) and k_sum_planes adds the planes in a fixed order.
 template <int NB>
 __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, const int* __restrict__ phase,
-                                                  const double* __restrict__ vrow, double* __restrict__ Gq) {
+                                                  const double* __restrict__ vrow, double* __restrict__ Gq, size_t plane_stride) {
   constexpr int DP = 16 * NB;
   constexpr int NT = NB * (NB + 1) / 2;
   const int lane = threadIdx.x & 63;
@@ -364,15 +366,17 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
         }
     }
   };
-  load_group(xbA, vA, 0);
-  for (int n1 = 0; n1 < dd.Mp; n1 += 32) {
+  const int ng = dd.Mp / 32, per = (ng + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int nbeg = 32 * min(ng, (int)blockIdx.y * per), nend = 32 * min(ng, ((int)blockIdx.y + 1) * per);
+  if (nbeg < nend) load_group(xbA, vA, nbeg);
+  for (int n1 = nbeg; n1 < nend; n1 += 32) {
     load_group(xbB, vB, n1 + 16);
     compute_group(xbA, vA);
-    if (n1 + 32 < dd.Mp) load_group(xbA, vA, n1 + 32);
+    if (n1 + 32 < nend) load_group(xbA, vA, n1 + 32);
     compute_group(xbB, vB);
   }
   // epilogue: scatter the permuted tiles into the natural row-major DPxDP matrix (+ I/alpha)
-  double* __restrict__ G = Gq + (size_t)c * DP * DP;
+  double* __restrict__ G = Gq + (size_t)blockIdx.y * plane_stride + (size_t)c * DP * DP;
   int t = 0;
 #pragma unroll
   for (int I = 0; I < NB; ++I)
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevData dd, int n_chains, cons
         const int row = NB * (rr + 4 * r) + I;
         const int col = NB * ci + J;
         double val = acc[t][r];
-        if (row == col) val += dd.inv_alpha;
+        if (row == col && blockIdx.y == 0) val += dd.inv_alpha;
         // diagonal tiles hold both triangles (rounded differently): keep the lower one and mirror it,
         // so that G is exactly symmetric
         if (I != J || row >= col) {

@@ -49,6 +49,7 @@ struct Group {
   double* qscale = nullptr;
   double *Gpart = nullptr, *Rpart = nullptr;  // k-split planes of small batches ([ksplit][n][DP*DP], [ksplit][n][Mp])
   int ksplit_a = 1, ksplit_l = 1;
+  int fsplit = 1;  // fp64 assembly of small batches: row ranges per chain (planes in Gpart)
   int* vbad = nullptr;
   int* vexp = nullptr;   // per-chain extra binary digits of the v grid (VSlice)
   d4* ctile = nullptr;   // c = v(1-2p) of trj.w in the tile layout of k_mompass, [ceil(n/16)][Mp/16][64] x 4 doubles
@@ -304,8 +305,15 @@ void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
                          g.ch.Gq);
       return;
     }
+    if (g.fsplit > 1) {  // small batch: row ranges into planes, summed in a fixed order
+      const size_t plane = (size_t)g.n * ctx->DP * ctx->DP;
+      dim3 grid((unsigned)((g.n + 3) / 4), (unsigned)g.fsplit);
+      NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, g.Gpart, plane));
+      hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.Gq, g.Gpart, g.fsplit, plane, plane);
+      return;
+    }
     dim3 grid((unsigned)((g.n + 3) / 4));
-    NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, g.ch.Gq));
+    NB_SWITCH(ctx, hipLaunchKernelGGL((k_assemble<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, v, g.ch.Gq, (size_t)0));
   });
 }
 
@@ -778,6 +786,16 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       RC(dalloc(ctx, &g.ch.gpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.ljl_part, (size_t)g.n * g.nsplit));
       if (!ctx->big && ctx->ccache) RC(dalloc(ctx, &g.ctile, (size_t)((g.n + 15) / 16) * (ctx->Mp / 16) * 64));
+      if (!ctx->big) {
+        // fp64 assembly (k_assemble: one chain per wavefront over all M rows): below ~1024 chains the launch has fewer wavefronts than
+        // the chip has SIMDs, so the rows are cut until ~2048 wavefronts exist (at least 256 rows per range, at most 16 ranges).
+        // D 64, M 10000, 512 chains: the step took longer than with 1024 chains (13.0 vs 7.6 ms, profiles/r01_i8_threshold.txt).
+        const long long waves = g.n;
+        long long fs = waves >= 1024 ? 1 : std::min<long long>(16, (2048 + waves - 1) / waves);
+        fs = std::min<long long>(fs, std::max(1, ctx->Mp / 256));
+        if (const char* e = getenv("RMHMC_FSPLIT")) { const long long v = atoll(e); if (v >= 1 && v <= 64) fs = v; }
+        g.fsplit = (int)fs;
+      }
       if (ngroups > 1) {
         g.ring.resize(64);
         for (auto& e : g.ring) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -847,6 +865,10 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         auto kfn2 = k_leverage_i8<S_, WN_, TN_>;
         HIPCK(hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
       });
+    }
+    for (Group& g : ctx->groups) {  // planes of the fp64 small-batch assembly (shared with the int8 k-split planes, whichever is larger)
+      const int need = std::max(g.fsplit, g.ksplit_a);
+      if (g.fsplit > 1 && (!g.Gpart || g.fsplit > g.ksplit_a)) RC(dalloc(ctx, &g.Gpart, (size_t)need * g.n * ctx->DP * ctx->DP));
     }
     RC(dalloc(ctx, &ctx->d_z, n * (size_t)D)); RC(dalloc(ctx, &ctx->d_ulen, n)); RC(dalloc(ctx, &ctx->d_gdir, n)); RC(dalloc(ctx, &ctx->d_uacc, n));
     if (ctx->big) {

@@ -538,3 +538,31 @@ def test_hmc_one_launch_trajectory_matches_generic_and_oracle(hip, oracle, monke
         assert rel_err(rt["w_prop"], r2["w_prop"]) < 1e-9 and rel_err(rt["p_prop"], r2["p_prop"]) < 1e-9
         assert rel_err(rt["H_prop"], r2["H_prop"]) < 1e-9
         assert np.array_equal(st[1], s2[1]) and np.array_equal(st[2], s2[2]) and rel_err(st[0], s2[0]) < 1e-8
+
+
+def test_small_batch_row_split_of_the_fp64_assembly(hip, oracle, monkeypatch):
+    """Fewer chains than SIMDs: k_assemble cuts the data rows into ranges (planes summed in a fixed order) so that the fp64 step time is
+    monotone in the batch size.  Same G as the unsplit kernel to summation-order rounding, same parity with the oracle,
+    and bit-reproducible from run to run."""
+    M, D, n = 3000, 64, 70
+    XX, t = synthetic_logreg(M, D, 5)
+    rs = np.random.RandomState(1)
+    w = 0.1 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
+
+    def run(lib, env):
+        if env is not None:
+            monkeypatch.setenv("RMHMC_FSPLIT", env)
+        else:
+            monkeypatch.delenv("RMHMC_FSPLIT", raising=False)
+        with lib.context(M, D, n, flags=0) as ctx:
+            ctx.set_data(XX, t)
+            return ctx.metric(w) + ctx.leapfrog(w, p, 0.4, 1, 2, 4)
+
+    split, split2, whole, ref = run(hip, None), run(hip, None), run(hip, "1"), run(oracle, None)
+    for a, b in zip(split, split2):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(split[0], whole[0])                       # the split is really on for 70 chains (different summation order)
+    assert rel_err(split[0], whole[0]) < 1e-14
+    for a, b in zip(split[:6], ref[:6]):
+        assert rel_err(a, b) < 1e-9
+    assert np.array_equal(split[0], np.swapaxes(split[0], 1, 2))
