@@ -679,30 +679,12 @@ __device__ __forceinline__ double neg_dot_lds(const double* a, const double* b, 
   return s0 + s1;
 }
 
-// lower Cholesky in place (left-looking; lane i owns row i).  np.linalg.cholesky, rmhmc.py:60,171.
-// rdiag (lane j): 1/L[j][j].  A pivot <=0 or NaN yields NaN everywhere downstream (=> H is NaN => the
-// proposal is rejected).
-__device__ __forceinline__ int chol_lds(double* A, int D, int lane, double& rdiag) {
-  int bad = 0;
-  rdiag = 1.0;
-  const double* rowp = A + lane * RM_LD;
-  for (int j = 0; j < D; ++j) {
-    const double s = neg_dot_lds(rowp, A + j * RM_LD, j, rowp[j]);  // meaningful for lanes j..D-1
-    const double sjj = rdlane(s, j);
-    if (!(sjj > 0.0)) bad = 1;
-    const double rinv = rsqrt(sjj);
-    __builtin_amdgcn_wave_barrier();
-    if (lane == j) { A[j * RM_LD + j] = sjj * rinv; rdiag = rinv; }
-    else if (lane > j && lane < D) A[lane * RM_LD + j] = s * rinv;
-    __builtin_amdgcn_wave_barrier();
-  }
-  return bad;
-}
-// The same factorisation, blocked by 16 columns (right-looking): the column steps of a block only carry the dot products over the
-// block's own columns (length < 16, for the diagonal block and the panel below it alike), and after each block the trailing
-// matrix gets its rank-16 update A_IJ -= P_I P_J' on the fp64 matrix cores, operands straight from the LDS image (one ds_read
-// per 16-row panel tile and k-step serves as A of tile row I and as B of tile column I).  Three times fewer serial LDS round
-// trips than chol_lds at D = 64.  Rows / columns D..16*NB-1 are padded with the identity here.
+// Lower Cholesky in place, lane i owns row i (np.linalg.cholesky, rmhmc.py:60,171), blocked by 16 columns (right-looking): the column
+// steps of a block only carry the dot products over the block's own columns (length < 16, for the diagonal block and the panel below it
+// alike), and after each block the trailing matrix gets its rank-16 update A_IJ -= P_I P_J' on the fp64 matrix cores, operands straight
+// from the LDS image (one ds_read per 16-row panel tile and k-step serves as A of tile row I and as B of tile column I).  rdiag (lane
+// j): 1/L[j][j].  A pivot <= 0 or NaN yields NaN everywhere downstream (=> H is NaN => the proposal is rejected).  Rows / columns
+// D..16*NB-1 are padded with the identity here.
 template <int NB, bool PK = false>
 __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& rdiag) {
   constexpr int DPc = 16 * NB;
@@ -760,7 +742,7 @@ __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& 
   if (lane >= D) rdiag = 1.0;
   return bad;
 }
-// x = (L L')^-1 b ; lane i holds b_i on entry and x_i on return; rdiag as produced by chol_lds
+// x = (L L')^-1 b ; lane i holds b_i on entry and x_i on return; rdiag as produced by chol_lds_blk
 template <bool PK = false>
 __device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane, double b, double rdiag) {
   const double* rowp = L + rm_row<PK>(lane);

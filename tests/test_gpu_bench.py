@@ -149,3 +149,17 @@ def test_sharded_sampler_gathers_from_hbm_through_rccl(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out == {"ok": True, "backend": "nccl", "world": 1, "shape": [37, 25, 10]}
+
+
+def test_bench_one_rank_rccl():
+    """bench.py's multi-rank branch with the REAL backend: one rank under torch.distributed.run with BENCH_FORCE_DIST=1 initialises RCCL
+    ("nccl"), runs the barriers, the max-over-ranks all-reduce and the write-out gather on CUDA tensors produced by rmhmc_chains_state_dev
+    and rmhmc_sample_stats_dev."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--workload", "c2",
+           "--ess-iters", "20", "--no-cpu-baseline", "--no-alternates"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["gathered_chains"] == 1024 and out["all_finite"] and out["min_ess"]["min_ess_per_sec"] > 0
