@@ -163,3 +163,19 @@ def test_bench_one_rank_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["gathered_chains"] == 1024 and out["all_finite"] and out["min_ess"]["min_ess_per_sec"] > 0
+
+
+def test_experiment_driver_on_the_gpu(hip):
+    """experiment.run_experiment (main.py:43-79) through the HIP library: run i is chain i of the seed whether the runs are executed one
+    after another (as main.py does) or as one batch; the summary carries the reference's quantities."""
+    from conftest import GOLDEN
+    from riemannhamiltonianmontecarlo_amd import experiment, tools
+    d = np.load(os.path.join(GOLDEN, "data_heart.npz"))
+    kw = dict(NumOfIterations=260, BurnIn=60, compat=False)
+    a = experiment.run_experiment(d["XX"], d["t"], "RMHMC", n_experiments=3, batched=False, seed=11, **kw)
+    b = experiment.run_experiment(d["XX"], d["t"], "RMHMC", n_experiments=3, batched=True, seed=11, **kw)
+    assert a["results_beta"].shape == (3, 200, 14) and np.array_equal(a["results_beta"], b["results_beta"])
+    assert a["results_time"].shape == (3,) and (a["results_time"] > 0).all() and np.all(b["results_time"] == b["results_time"][0])
+    assert np.array_equal(a["ESS"], tools.CalculateESS(a["results_beta"].mean(axis=0), 199))
+    assert a["Time per Min ESS"] == round(a["avg_time_taken"] / a["ESS"].min(), 6)
+    assert 20 < a["per_run"]["Min"] <= 200            # RMHMC on heart: nearly independent samples (paper Table 6: 4862 of 5000)
