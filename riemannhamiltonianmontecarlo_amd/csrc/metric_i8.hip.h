@@ -52,8 +52,16 @@ __device__ __forceinline__ int i8_lds_off(int row, int half) { return row * I8_R
 // of them are resident at a time, so XCD x gets the chain blocks x, x+8, ... and walks its (chain block, pair block) grid in
 // super-tiles of I8_GC x I8_GP tiles: the 32 resident workgroups then share 4 V tiles and 8 Z tiles per stage through that
 // XCD's L2 instead of fetching 19 distinct ones.
+#ifndef I8_GC
 #define I8_GC 4
 #define I8_GP 8
+#endif
+#ifndef I8_DSPREAD
+#define I8_DSPREAD 1   // the LDS-DMA loads of stage ks+2 are issued one slice per product group instead of all at the top of the stage, where
+                       // they collided with every wave's burst of fragment reads: 3.07-3.14 -> 3.01-3.06 ms per launch at config 3, S = 6
+                       // (two slices per long group, after the group's MFMAs, or one per MFMA pair of the first group: no better;
+                       // product groups in reverse order: worse; profiles/r02_i8_tile_ablation.txt).  0: all at the top (round 1)
+#endif
 __device__ __forceinline__ bool i8_tile_of_block(int b, int nCB, int nPB, int& cb, int& pb) {
   if (nCB < 8) {  // fewer chain blocks than XCDs: the grouping below would leave whole XCDs idle, so the tiles are simply dealt round
     if (b >= nCB * nPB) return false;
@@ -130,15 +138,17 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
     gslice[k] = isA ? strideV : strideZ;
     lbase[k] = __builtin_amdgcn_readfirstlane((u & ~63) * 16);
   }
-  auto gl = [&](int ks, int buf) {
+  auto gl1 = [&](int ks, int buf, int s) {  // slice s of stage ks
     if (I8_ABLATE & 1) return;
 #pragma unroll
-    for (int s = 0; s < S; ++s)
+    for (int k = 0; k < NU; ++k)
+      if (on[k])
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gsrc[k] + s * gslice[k] + (size_t)ks * gstep[k]),
+                                         (lds_ptr_t)(lds + buf * STAGE + s * ROWS * I8_ROWB + lbase[k]), 16, 0, 0);
+  };
+  auto gl = [&](int ks, int buf) {
 #pragma unroll
-      for (int k = 0; k < NU; ++k)
-        if (on[k])
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gsrc[k] + s * gslice[k] + (size_t)ks * gstep[k]),
-                                           (lds_ptr_t)(lds + buf * STAGE + s * ROWS * I8_ROWB + lbase[k]), 16, 0, 0);
+    for (int s = 0; s < S; ++s) gl1(ks, buf, s);
   };
   // all but the newest stage's loads of this wave have landed (the waves of a partly filled last unit row issue fewer)
   auto retire_older = [&]() {
@@ -167,7 +177,8 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   i4v fb[S][TN], fa[2][2];
   for (int ks = 0; ks < nks; ++ks) {
     const int nxt = cur == 2 ? 0 : cur + 1, wr = nxt == 2 ? 0 : nxt + 1;
-    if (ks + 2 < nks) gl(ks + 2, wr);
+    const bool spread = I8_DSPREAD && (WN != 4 || work);  // (waves that skip their MFMAs issue their loads at the top)
+    if (!spread && ks + 2 < nks) gl(ks + 2, wr);
     const unsigned char* bc = lds + ((I8_ABLATE & 2) ? 0 : cur) * STAGE;
     if (WN != 4 || work) {
     const bool rd = !(I8_ABLATE & 2) || ks == 0;
@@ -187,6 +198,7 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
 #pragma unroll
         for (int a = 0; a < 2; ++a) fa[(i + 1) & 1][a] = *(const i4v*)(bc + (i + 1) * ROWS * I8_ROWB + fragA + a * 32 * I8_ROWB);
       }
+      if (spread && ks + 2 < nks) gl1(ks + 2, wr, i);
       if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = S - 1 - i; j >= 0; --j) {

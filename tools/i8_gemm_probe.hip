@@ -86,6 +86,11 @@ int main(int argc, char** argv) {
       run_case<5, 4, 1, 1>(8192, 2080, 10000, false, 8);
       return 0;
     }
+    if (S == 61) {  // without the pinned issue order (sched_barrier)
+      run_case<6, 4, 1, 0>(8192, 2080, 10000, false, 8);
+      run_case<6, 4, 1, 1>(300, 300, 1000, true, 0);
+      return 0;
+    }
     if (S == 22) {  // 4 waves, 64x64 wave tile, one wave per SIMD (512 registers): a third fewer LDS fragment reads per MFMA
       run_case<6, 2, 2, 1>(300, 300, 1000, true, 0);
       run_case<6, 2, 2, 1>(8192, 2080, 10000, false, 5);
