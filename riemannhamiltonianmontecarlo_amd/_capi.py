@@ -392,5 +392,5 @@ def load_hip_library():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _hip = RmhmcLib(HIP_LIB_PATH)
+        _hip = RmhmcLib(os.environ.get("RMHMC_HIP_LIB", HIP_LIB_PATH))   # (override: experiment builds of the same library)
     return _hip

@@ -19,9 +19,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define RM_PI2 6.283185307179586476925286766559
 // Packed form of the same LDS image (PK = true in the routines below): only the lower BLOCK triangle of 16 x 16 blocks is kept - the
 // Cholesky / solve / inverse routines never touch a block above the diagonal -, row i of block row I = i >> 4 holding its 16 (I + 1)
-// columns with leading dimension 16 I + 18 (16-byte aligned, the same bank pattern as RM_LD).  21.5 KB instead of 33.8 KB per matrix:
-// seven chains per CU instead of four for the latency-bound per-chain kernels.  Reads past a row's end (lanes that run a loop whose
-// result they discard) stay inside the allocation thanks to the 64 doubles of slack.
+// columns with leading dimension 16 I + 18 (16-byte aligned rows).  21.5 KB instead of 33.8 KB per matrix: seven chains per CU instead
+// of four for the latency-bound per-chain kernels (factor + solve + inverse 1.76 -> 1.52 ms per step at config 3, same box).  Measured
+// against it on the same box: leading dimensions 34 / 34 / 66 / 66 (every row in 16-byte slot i mod 16 as with RM_LD: a quarter of the
+// bank conflicts, 25.6 KB, six chains per CU) took 1.94 ms - slower than the unpacked image; the smaller image wins despite its
+// conflicts.  Reads past a row's end (lanes that run a loop whose result they discard) stay inside the allocation thanks to the 64
+// doubles of slack.
 #define RM_PK_DOUBLES (2688 + 64)
 template <bool PK>
 __device__ __forceinline__ int rm_row(int i) {
@@ -31,31 +34,6 @@ __device__ __forceinline__ int rm_row(int i) {
 }
 template <bool PK>
 __device__ __forceinline__ int rm_len(int i) { return PK ? 16 * ((i >> 4) + 1) : 64; }  // columns of row i that exist
-
-struct DevData {
-  const double* Xr;
-  const double* Xt;
-  const double* t;
-  int M, Mp, D, DP, nblk;   // nblk = Mp/64
-  double inv_alpha;
-  double log_prior_const;   // -0.5*log(2*pi*alpha)
-};
-
-// point record: everything the sampler needs at a position w (rmhmc.py:50-77 / :134-156)
-struct Rec {
-  double *w, *grad, *tr, *L, *Ginv, *ljl, *hld;
-};
-
-struct Chains {
-  Rec cur, trj;
-  double *p, *p0, *Hcur, *Hprop, *tau;
-  int *steps_left, *phase, *status, *nsteps_last;
-  long long *iter, *accepted, *steps_done;
-  // scratch
-  double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv2, *ljl_part, *qpart, *gpart;
-  int n;
-  int hiprio;  // light kernels raise their wave priority when they co-run with another group's MFMA kernel
-};
 
 // ---------------------------------------------------------------------------------------------
 // wave helpers
