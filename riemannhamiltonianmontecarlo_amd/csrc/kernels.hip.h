@@ -35,6 +35,31 @@ __device__ __forceinline__ int rm_row(int i) {
 template <bool PK>
 __device__ __forceinline__ int rm_len(int i) { return PK ? 16 * ((i >> 4) + 1) : 64; }  // columns of row i that exist
 
+struct DevData {
+  const double* Xr;
+  const double* Xt;
+  const double* t;
+  int M, Mp, D, DP, nblk;   // nblk = Mp/64
+  double inv_alpha;
+  double log_prior_const;   // -0.5*log(2*pi*alpha)
+};
+
+// point record: everything the sampler needs at a position w (rmhmc.py:50-77 / :134-156)
+struct Rec {
+  double *w, *grad, *tr, *L, *Ginv, *ljl, *hld;
+};
+
+struct Chains {
+  Rec cur, trj;
+  double *p, *p0, *Hcur, *Hprop, *tau;
+  int *steps_left, *phase, *status, *nsteps_last;
+  long long *iter, *accepted, *steps_done;
+  // scratch
+  double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv2, *ljl_part, *qpart, *gpart;
+  int n;
+  int hiprio;  // light kernels raise their wave priority when they co-run with another group's MFMA kernel
+};
+
 // ---------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------
