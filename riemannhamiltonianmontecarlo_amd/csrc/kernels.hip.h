@@ -574,7 +574,9 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
 template <int NB>
 __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, const int* __restrict__ phase,
                                                   const double* __restrict__ Ginv, const double* __restrict__ crow,
-                                                  double* __restrict__ tr) {
+                                                  double* __restrict__ tr, double* __restrict__ trpart) {
+  // gridDim.y > 1 (small batches, as in k_assemble): row range y writes its partial trace term to trpart[y][chain][d], summed in a
+  // fixed order by k_reduce_tr
   constexpr int DP = 16 * NB;
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -631,20 +633,23 @@ __global__ __launch_bounds__(256) void k_leverage(DevData dd, int n_chains, cons
 #pragma unroll
       for (int J = 0; J < NB; ++J) tracc[r][J] = fma(ch, X[r][J], tracc[r][J]);
   };
-  load_block(XA, cA, 0);
-  for (int n0 = 0; n0 < dd.Mp; n0 += 32) {
+  const int ng = dd.Mp / 32, per = (ng + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int nbeg = 32 * min(ng, (int)blockIdx.y * per), nend = 32 * min(ng, ((int)blockIdx.y + 1) * per);
+  if (nbeg < nend) load_block(XA, cA, nbeg);
+  for (int n0 = nbeg; n0 < nend; n0 += 32) {
     load_block(XB, cB, n0 + 16);
     compute_block(XA, cA);
-    if (n0 + 32 < dd.Mp) load_block(XA, cA, n0 + 32);
+    if (n0 + 32 < nend) load_block(XA, cA, n0 + 32);
     compute_block(XB, cB);
   }
+  double* __restrict__ out = gridDim.y > 1 ? trpart + ((size_t)blockIdx.y * n_chains + c) * DP : tr + (size_t)c * DP;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
       const double a = row16_sum(tracc[r][J]);
       const int d = NB * (4 * r + rr) + J;
-      if (ci == 0 && d < dd.D) tr[(size_t)c * DP + d] = a;
+      if (ci == 0 && d < dd.D) out[d] = a;
     }
 }
 

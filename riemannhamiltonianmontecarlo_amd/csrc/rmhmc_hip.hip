@@ -371,11 +371,16 @@ void launch_leverage(rmhmc_ctx* ctx, Group& g) {
     });
     return;
   }
+  const int fs = std::min(g.fsplit, g.nsplit);  // (the partials go to gpart, which holds nsplit planes)
   launch(ctx, g, HEAVY, "leverage", [&](hipStream_t st) {
-    dim3 grid((unsigned)((g.n + 3) / 4));
+    dim3 grid((unsigned)((g.n + 3) / 4), (unsigned)fs);
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_leverage<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.Ginv, g.ch.rv2,
-                                      g.ch.trj.tr));
+                                      g.ch.trj.tr, g.ch.gpart));
   });
+  if (fs > 1)
+    launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
+      hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, fs);
+    });
 }
 
 // one wavefront (64-thread block) per chain
@@ -773,9 +778,11 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       long long ns = (6144 / ngroups + cgroups - 1) / cgroups;
       if (ns < 1) ns = 1;
       if (ns > nb16) ns = nb16;
-      {  // ... but for short data sets no more than 64 splits: the consumers sum the partials serially (600 chains x 1000 rows x D 25:
-         // 0.61 -> 0.52 ms per step; long data sets in small batches need the parallelism: 128 chains x 10000 rows 5.9 -> 8.3 ms when capped)
-        long long cap = ctx->Mp <= 4096 ? 64 : nb16;
+      {  // ... but no more than 64 splits: the consumers sum the partials serially.  (Round 1 kept up to Mp/16 splits for long data sets
+         // in small batches, when the one-chain-per-wave assembly dominated those shapes anyway; with the row ranges of k_assemble /
+         // k_leverage it is the serial sums that cost: D 64, M 10000, 64 / 128 / 256 chains: 2.44 / 2.28 / 2.52 -> 1.69 / 1.49 / 1.99 ms
+         // per step, the int8 path at 128-512 chains 10-30 % less; profiles/r02_fp64_batch_sweep.txt)
+        long long cap = 64;
         if (const char* e = getenv("RMHMC_NSPLIT_MAX")) { const long long v = atoll(e); if (v >= 1) cap = v; }
         if (ns > cap) ns = cap;
       }

@@ -566,3 +566,20 @@ def test_small_batch_row_split_of_the_fp64_assembly(hip, oracle, monkeypatch):
     for a, b in zip(split[:6], ref[:6]):
         assert rel_err(a, b) < 1e-9
     assert np.array_equal(split[0], np.swapaxes(split[0], 1, 2))
+
+
+@pytest.mark.parametrize("K,L", [(1, 1), (1, 3), (2, 6), (6, 2)])
+def test_fixed_point_count_and_trajectory_length_edge_cases(hip, oracle, K, L):
+    """NumOfNewtonSteps = 1 (the c cache of the momentum passes has a first iteration only), other counts, L = 1, one saved sample:
+    sampler vs the oracle with the same Philox streams on the generic (D = 40, int8 and fp64) path."""
+    M, D, n = 700, 40, 130
+    XX, t = synthetic_logreg(M, D, 8)
+    out = []
+    for lib, fl in ((hip, 0), (hip, _capi.int8_metric_flags(6)), (oracle, 0)):
+        with lib.context(M, D, n, flags=fl) as ctx:
+            ctx.set_data(XX, t)
+            out.append(ctx.sample(7, 6, L, 0.4, K, seed=K * 10 + L))       # S = 1
+    for g in out[:2]:
+        assert g[0].shape == (n, 1, D)
+        assert np.array_equal(g[1], out[2][1]) and np.array_equal(g[2], out[2][2])
+        assert rel_err(g[0], out[2][0]) < 1e-8
