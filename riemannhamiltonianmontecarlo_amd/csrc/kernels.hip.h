@@ -1067,6 +1067,8 @@ struct IterParams {
   double* samples;        // [n][S][D] (unpadded) or nullptr
   const double *z_in, *ulen_in, *gdir_in, *uacc_in;  // explicit randomness (unit API) or nullptr
   int* done_count;
+  const int* orig;        // work-sorted layout of the bulk sampler (rmhmc_hip.hip, sample_core): the chain at position c is chain orig[c] of the
+                          // caller's order - its Philox key and its block of `samples` - or nullptr: position = chain
 };
 
 __device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, int D, int DP, int lane) {
@@ -1116,13 +1118,14 @@ __device__ __forceinline__ double half_quadform(const double* __restrict__ Gi, i
 }
 
 // D standard normals of (seed, chain, iteration) into zs[] (or the caller-supplied draws)
-__device__ __forceinline__ void draw_normals(const IterParams& ip, int c, long long it, int D, int lane, double* zs) {
+__device__ __forceinline__ void draw_normals(const IterParams& ip, int c, long long it, int D, int lane, double* zs, long long oc = -1) {
+  const long long id = oc >= 0 ? oc : c;  // chain index in the caller's order (IterParams::orig)
   for (int d = lane; d < D; d += 64) {
     if (ip.z_in) {
       zs[d] = ip.z_in[(size_t)c * D + d];
     } else {
       double U0, U1;
-      rng_block(ip.seed, (unsigned long long)(ip.chain_offset + c), (uint32_t)it, (uint32_t)(d >> 1), U0, U1);
+      rng_block(ip.seed, (unsigned long long)(ip.chain_offset + id), (uint32_t)it, (uint32_t)(d >> 1), U0, U1);
       const double R = sqrt(-2.0 * log(U0));
       double sn, cs;
       sincos(RM_PI2 * U1, &sn, &cs);
@@ -1139,14 +1142,15 @@ __device__ __forceinline__ void iter_begin_dev(int D, int DP, const Chains& ch, 
   if (it >= ip.iter_limit) return;
   // trajectory starts from the cached record of the current point (wNew = w.copy(), rmhmc.py:47)
   copy_rec(ch.trj, ch.cur, c, D, DP, lane);
+  const long long oc = ip.orig ? ip.orig[c] : c;
   // draws: z ~ randn(1,D), u_len ~ rand(), g_dir ~ randn()   (rmhmc.py:80,89,90)
-  draw_normals(ip, c, it, D, lane, zs);
+  draw_normals(ip, c, it, D, lane, zs, oc);
   double u_len, g_dir;
   if (ip.z_in) {
     u_len = ip.ulen_in[c];
     g_dir = ip.gdir_in[c];
   } else {
-    const unsigned long long gid = (unsigned long long)(ip.chain_offset + c);
+    const unsigned long long gid = (unsigned long long)(ip.chain_offset + oc);
     double U0, U1, Ua;
     rng_block(ip.seed, gid, (uint32_t)it, 0x40000000u, u_len, Ua);
     rng_block(ip.seed, gid, (uint32_t)it, 0x40000001u, U0, U1);
@@ -1220,6 +1224,7 @@ __device__ __forceinline__ void iter_end_dev(int D, int DP, const Chains& ch, co
   const int ph = ch.phase[c];
   if (!(ph == 2 || (ph == 1 && ch.steps_left[c] == 0))) return;
   const long long it = ch.iter[c];
+  const long long oc = ip.orig ? ip.orig[c] : c;
   for (int d = lane; d < D; d += 64) ps[d] = ch.p[(size_t)c * DP + d];
   __builtin_amdgcn_wave_barrier();
   const double quad = half_quadform(ch.trj.Ginv + (size_t)c * DP * DP, D, DP, lane, ps);
@@ -1230,14 +1235,14 @@ __device__ __forceinline__ void iter_end_dev(int D, int DP, const Chains& ch, co
     u_acc = ip.uacc_in[c];
   } else {
     double U0;
-    rng_block(ip.seed, (unsigned long long)(ip.chain_offset + c), (uint32_t)it, 0x40000000u, U0, u_acc);
+    rng_block(ip.seed, (unsigned long long)(ip.chain_offset + oc), (uint32_t)it, 0x40000000u, U0, u_acc);
   }
   const bool accept = (ratio > 0.0) || (ratio > log(u_acc));  // rmhmc.py:181
   if (accept) copy_rec(ch.cur, ch.trj, c, D, DP, lane);
   __builtin_amdgcn_wave_barrier();  // (a lane reads back only what it wrote itself)
   if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S)
     for (int d = lane; d < D; d += 64)
-      ip.samples[((size_t)c * ip.S + (size_t)(it - ip.burn_in)) * D + d] = ch.cur.w[(size_t)c * DP + d];
+      ip.samples[((size_t)oc * ip.S + (size_t)(it - ip.burn_in)) * D + d] = ch.cur.w[(size_t)c * DP + d];
   if (lane == 0) {
     ch.Hprop[c] = Hp;
     if (accept) ch.accepted[c] += 1;
@@ -1604,6 +1609,25 @@ __global__ void k_min_iter(const long long* __restrict__ iter, size_t n, unsigne
     m = x < m ? x : m;
   }
   if ((threadIdx.x & 63) == 0) atomicMin(out, m);
+}
+// T[c] = leapfrog steps chain chain_offset + c executes in transitions it0 .. it1-1: the trajectory lengths are drawn independently of
+// the state (RandomStep = ceil(rand() L), rmhmc.py:89), so they are known before the run (same draw as iter_begin_dev)
+__global__ void k_traj_steps(unsigned long long seed, long long chain_offset, int L, long long it0, long long it1, size_t n,
+                             long long* __restrict__ T) {
+  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  long long t = 0;
+  for (long long it = it0; it < it1; ++it) {
+    double u_len, ua;
+    rng_block(seed, (unsigned long long)(chain_offset + (long long)c), (uint32_t)it, 0x40000000u, u_len, ua);
+    t += (long long)ceil(u_len * (double)L);
+  }
+  T[c] = t;
+}
+// dst[orig[i]] = src[i]
+__global__ void k_scatter_ll(long long* __restrict__ dst, const long long* __restrict__ src, const int* __restrict__ orig, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[orig[i]] = src[i];
 }
 // a[i] = b[i] - a[i]
 __global__ void k_sub_ll(long long* __restrict__ a, const long long* __restrict__ b, size_t n) {

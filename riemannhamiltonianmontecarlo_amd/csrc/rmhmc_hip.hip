@@ -107,6 +107,11 @@ struct rmhmc_ctx {
   int *d_nsteps = nullptr, *d_dir = nullptr, *d_done = nullptr;
   long long* d_steps0 = nullptr;
   unsigned long long* d_miniter = nullptr;
+  // work-sorted layout of the bulk sampler (sample_core)
+  int* d_orig = nullptr;            // [n] position -> chain index in the caller's order
+  long long* d_T = nullptr;         // [2n] scratch: trajectory-length sums / un-permuted counters
+  bool sorted = false;              // in use by the running sampler (iter_params)
+  bool counters_sorted = false;     // the last sampler run left its counters un-permuted in d_T
   // progress reports of the bulk samplers (rmhmc_set_progress)
   rmhmc_progress_fn progress_fn = nullptr;
   void* progress_user = nullptr;
@@ -526,6 +531,11 @@ IterParams iter_params(rmhmc_ctx* ctx, const Group& g, const IterBase& b) {
   ip.burn_in = b.burn_in;
   ip.S = b.S;
   ip.samples = b.samples ? b.samples + (size_t)g.off * b.S * ctx->D : nullptr;
+  if (ctx->sorted) {  // (single group: g.off = 0) chain ids and sample blocks through the position -> chain map
+    ip.orig = ctx->d_orig;
+    ip.chain_offset = ctx->chain_offset;
+    ip.samples = b.samples;
+  }
   if (b.explicit_rng) {
     ip.z_in = ctx->d_z + (size_t)g.off * ctx->D; ip.ulen_in = ctx->d_ulen + g.off; ip.gdir_in = ctx->d_gdir + g.off; ip.uacc_in = ctx->d_uacc + g.off;
   }
@@ -885,6 +895,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     }
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
     RC(dalloc(ctx, &ctx->d_miniter, 1));
+    RC(dalloc(ctx, &ctx->d_orig, n)); RC(dalloc(ctx, &ctx->d_T, 2 * n));
     {  // mid-size problems in small batches: one launch per leapfrog step (RMHMC_MEDIUM=0 disables it)
       // measured per global step at one chain (tools/bench_single.py): australian (D = 15) 108 us vs 218 us generic, heart (D = 14)
       // 85 vs 154, german (D = 25) 236 vs 386
@@ -1300,34 +1311,117 @@ static int run_phase(rmhmc_ctx* ctx, const IterBase& ib, long long from) {
   return RMHMC_OK;
 }
 
+// One global step on the first na chains only (na a multiple of 128 or n).  The single group's view is narrowed for the launches of the
+// step: every kernel takes its chain count and its partial-plane strides from the group, so producers and consumers agree.
+static void launch_global_step_prefix(rmhmc_ctx* ctx, const IterBase& ib, int na) {
+  Group& g = ctx->groups[0];
+  const Group saved = g;
+  g.n = na; g.ch.n = na;
+  if (g.nCp) g.nCp = (na + I8_BM - 1) / I8_BM * I8_BM;
+  // (row ranges, k-split planes and row splits stay as chosen for the whole batch: every chain's sums keep their order, so the
+  // results are bit-identical to the unsorted run)
+  launch_global_step(ctx, ib);
+  g = saved;
+}
+
+// Work-sorted phase B.  The trajectory lengths do not depend on the state (RandomStep = ceil(rand() L), rmhmc.py:89), so the number of
+// leapfrog steps T_c every chain needs for its post-burn-in transitions is known beforehand.  With the chains laid out in order of
+// decreasing T_c, the chains still running after s global steps are a prefix of the batch, and the launches of the tail shrink with it:
+// the phase costs sum_c T_c chain-steps instead of n max_c T_c (8192 chains, 199 transitions: 791 global steps for a mean of 696, i.e.
+// 12 % of the TimeTaken window spent on finished chains).  Samples do not change: chains are independent and their randomness is keyed
+// by the chain's index in the caller's order (IterParams::orig).
+static int run_sorted_phase(rmhmc_ctx* ctx, const IterBase& ib, const std::vector<long long>& T /* descending */) {
+  const int n = (int)ctx->n;
+  const long long Tmin = T[n - 1], Tmax = T[0];
+  fork_streams(ctx);
+  {
+    StepGraph sg;
+    if (step_graph_usable(ctx, Tmin)) (void)build_step_graph(ctx, ib, sg);
+    run_generic_steps(ctx, ib, Tmin, &sg);
+    HIPCK(hipStreamSynchronize(ctx->stream));  // (the graph goes out of scope)
+  }
+  int na = n;
+  for (long long s = Tmin; s < Tmax; ++s) {
+    while (na > 0 && T[na - 1] <= s) --na;  // chains with T > s are still running: positions [0, na)
+    const int nar = std::min(n, (na + 127) / 128 * 128);
+    if (nar == n) launch_global_step(ctx, ib);
+    else launch_global_step_prefix(ctx, ib, nar);
+  }
+  join_streams(ctx);
+  int done = 0;
+  long long mi = 0;
+  RC(poll_progress(ctx, &done, &mi));
+  if (done < n) RC(run_until_done(ctx, ib, 1));  // (safety net: never taken if the schedule above is right)
+  return RMHMC_OK;
+}
+
 // Runs the sampler; the saved states go to the device buffer d_samples ([n][S][D], caller-provided).  Per-chain counters are left
 // on the device: ch.accepted, and the post-burn-in leapfrog steps in d_steps0 (steps_done at the end minus at the burn-in mark).
 static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const double* theta0, double* d_samples, double* seconds_out) {
   const long long S = n_iter - burn_in;
-  RC(init_chains(ctx, theta0));
-  // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
-  // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
-  const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
-  RC(run_phase(ctx, ipA, 0));
-  HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
-  RC(sync(ctx));
-  if (ctx->progress_fn) RC(report_progress(ctx, RMHMC_EV_BURNIN_DONE, burn_in + 1));  // rmhmc.py:194-196: banner, then the timer starts
-  const auto t0 = std::chrono::steady_clock::now();
-  if (n_iter > burn_in + 1) {
-    const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
-    RC(run_phase(ctx, ipB, burn_in + 1));
+  const int n = (int)ctx->n;
+  // work-sorted layout (see run_sorted_phase): generic and one-launch stepping paths of the RMHMC sampler, one chain group, no
+  // progress reports (they cut the run at fixed iteration counts)
+  std::vector<long long> T;
+  std::vector<double> th_perm;
+  bool sorted = ctx->sampler == 0 && ctx->groups.size() == 1 && !ctx->fused && !ctx->progress_fn && n >= 2 && n_iter > burn_in + 1;
+  if (const char* e = getenv("RMHMC_SORTED")) sorted = sorted && atoi(e) != 0;
+  if (sorted) {
+    hipLaunchKernelGGL(k_traj_steps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)ctx->seed,
+                       (long long)ctx->chain_offset, ctx->L, (long long)burn_in + 1, (long long)n_iter, (size_t)n, ctx->d_T);
+    std::vector<long long> t0(n);
+    RC(download(ctx, t0.data(), ctx->d_T, (size_t)n));
+    RC(sync(ctx));
+    std::vector<int> orig(n);
+    for (int i = 0; i < n; ++i) orig[i] = i;
+    std::stable_sort(orig.begin(), orig.end(), [&](int a, int b) { return t0[a] > t0[b]; });
+    T.resize(n);
+    for (int i = 0; i < n; ++i) T[i] = t0[orig[i]];
+    RC(upload(ctx, ctx->d_orig, orig.data(), (size_t)n));
+    RC(sync(ctx));
+    th_perm.resize((size_t)n * ctx->D);
+    for (int i = 0; i < n; ++i)
+      for (int d = 0; d < ctx->D; ++d) th_perm[(size_t)i * ctx->D + d] = theta0 ? theta0[(size_t)orig[i] * ctx->D + d] : 1e-3;  // rmhmc.py:27
+    theta0 = th_perm.data();
   }
-  RC(sync(ctx));
-  if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  hipLaunchKernelGGL(k_sub_ll, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_steps0, ctx->ch.steps_done, (size_t)ctx->n);
-  return RMHMC_OK;
+  ctx->sorted = sorted;
+  int rc = [&]() -> int {
+    RC(init_chains(ctx, theta0));
+    // phase A: every chain completes transitions 0..burn_in; chains that get there first wait, so that
+    // the timed phase B covers exactly the post-burn-in transitions (TimeTaken, rmhmc.py:194-198)
+    const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
+    RC(run_phase(ctx, ipA, 0));
+    HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
+    RC(sync(ctx));
+    if (ctx->progress_fn) RC(report_progress(ctx, RMHMC_EV_BURNIN_DONE, burn_in + 1));  // rmhmc.py:194-196: banner, then the timer starts
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_iter > burn_in + 1) {
+      const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
+      if (sorted) RC(run_sorted_phase(ctx, ipB, T));
+      else RC(run_phase(ctx, ipB, burn_in + 1));
+    }
+    RC(sync(ctx));
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    hipLaunchKernelGGL(k_sub_ll, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_steps0, ctx->ch.steps_done, (size_t)ctx->n);
+    if (sorted) {  // counters back into the caller's order: d_T[0..n) accepted, d_T[n..2n) post-burn-in steps
+      const dim3 grid((unsigned)((n + 255) / 256));
+      hipLaunchKernelGGL(k_scatter_ll, grid, dim3(256), 0, ctx->stream, ctx->d_T, ctx->ch.accepted, ctx->d_orig, (size_t)n);
+      hipLaunchKernelGGL(k_scatter_ll, grid, dim3(256), 0, ctx->stream, ctx->d_T + n, ctx->d_steps0, ctx->d_orig, (size_t)n);
+    }
+    return RMHMC_OK;
+  }();
+  ctx->sorted = false;
+  ctx->counters_sorted = sorted && rc == RMHMC_OK;
+  return rc;
 }
 // the counters of sample_core to host or device int64 arrays (either may be NULL)
 static int sample_counters(rmhmc_ctx* ctx, int64_t* accept_out, int64_t* steps_out, hipMemcpyKind kind) {
   static_assert(sizeof(long long) == sizeof(int64_t), "int64");
-  if (accept_out) HIPCK(hipMemcpyAsync(accept_out, ctx->ch.accepted, sizeof(int64_t) * ctx->n, kind, ctx->stream));
-  if (steps_out) HIPCK(hipMemcpyAsync(steps_out, ctx->d_steps0, sizeof(int64_t) * ctx->n, kind, ctx->stream));
+  const long long* acc = ctx->counters_sorted ? ctx->d_T : ctx->ch.accepted;
+  const long long* stp = ctx->counters_sorted ? ctx->d_T + ctx->n : ctx->d_steps0;
+  if (accept_out) HIPCK(hipMemcpyAsync(accept_out, acc, sizeof(int64_t) * ctx->n, kind, ctx->stream));
+  if (steps_out) HIPCK(hipMemcpyAsync(steps_out, stp, sizeof(int64_t) * ctx->n, kind, ctx->stream));
   return RMHMC_OK;
 }
 

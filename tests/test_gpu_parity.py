@@ -583,3 +583,30 @@ def test_fixed_point_count_and_trajectory_length_edge_cases(hip, oracle, K, L):
         assert g[0].shape == (n, 1, D)
         assert np.array_equal(g[1], out[2][1]) and np.array_equal(g[2], out[2][2])
         assert rel_err(g[0], out[2][0]) < 1e-8
+
+
+@pytest.mark.parametrize("M,D,n,fl", [(600, 40, 300, 0), (600, 40, 300, _capi.int8_metric_flags(6)), (500, 12, 40, _capi.COMPAT),
+                                       (400, 100, 20, 0)])
+def test_work_sorted_sampler_is_bit_identical(hip, monkeypatch, M, D, n, fl):
+    """The bulk sampler lays the chains out in order of decreasing post-burn-in work (the trajectory lengths are drawn independently of
+    the state, so they are known beforehand) and shrinks the launches of the tail with the prefix of chains still running.  Chains are
+    independent and keyed by their index in the caller's order: samples, acceptance counts, step counts and the device statistics must
+    be bit-identical to the unsorted run (generic fp64 / int8, one-launch and large-D stepping paths)."""
+    XX, t = synthetic_logreg(M, D, 3)
+    th = 0.01 * np.random.RandomState(0).randn(n, D)
+
+    def run(env):
+        monkeypatch.setenv("RMHMC_SORTED", env)
+        with hip.context(M, D, n, flags=fl) as ctx:
+            ctx.set_data(XX, t)
+            a = ctx.sample(40, 12, 6, 0.4, 4, seed=21, chain_offset=5, theta0=th)
+            b = ctx.sample_stats(40, 12, 6, 0.4, 4, seed=21, chain_offset=5, theta0=th)
+        return a, b
+
+    (s1, a1, st1, _), b1 = run("1")
+    (s0, a0, st0, _), b0 = run("0")
+    assert np.array_equal(s1, s0) and np.array_equal(a1, a0) and np.array_equal(st1, st0)
+    assert len(set(st1.tolist())) > 3                       # the chains really differ in work
+    for k in ("mean", "var", "ess", "accepted", "leapfrog_steps"):
+        assert np.array_equal(b1[k], b0[k], equal_nan=True), k
+    assert np.array_equal(b1["accepted"], a1) and np.array_equal(b1["leapfrog_steps"], st1)
