@@ -89,6 +89,14 @@ def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0, literal_budget_s=10.0):
     out = {"value": n * steps / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
            "sample": "%d chains x %d leapfrog steps of the same (M=%d, D=%d) workload, matrix-free C oracle, OpenMP over chains, %.1f s"
                      % (n, steps, M, D, dt)}
+    # the same oracle on ONE core (one chain: the OpenMP loop over chains has a single iteration), SURVEY 8(d) asks for both
+    st1 = max(2, int(steps * n / cores / 8))
+    with oracle.context(M, D, 1, flags=flags) as ctx:
+        ctx.set_data(XX, t)
+        ctx.chains_init(seed=1, L=L, eps=eps, K=K)
+        t0 = time.perf_counter(); ctx.chains_run(st1); dt1 = time.perf_counter() - t0
+    out["one_core"] = {"value": st1 / dt1, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
+                       "sample": "1 chain x %d leapfrog steps, matrix-free C oracle, %.1f s" % (st1, dt1)}
     # the reference's own O(M D^3) formulation (forms the DxDxD tensor, LU inverse/solve: the literal variant of the
     # oracle, i.e. what code/rmhmc.py does, in C instead of NumPy) on a smaller sample, for an apples-to-apples number
     if literal_budget_s > 0 and D <= 64:
