@@ -610,3 +610,27 @@ def test_work_sorted_sampler_is_bit_identical(hip, monkeypatch, M, D, n, fl):
     for k in ("mean", "var", "ess", "accepted", "leapfrog_steps"):
         assert np.array_equal(b1[k], b0[k], equal_nan=True), k
     assert np.array_equal(b1["accepted"], a1) and np.array_equal(b1["leapfrog_steps"], st1)
+
+
+def test_c_cache_and_graph_replay_do_not_change_results(hip, monkeypatch):
+    """k_mompass with c = v(1-2p) cached per position (RMHMC_CCACHE, default on) against recomputing it in every pass, and the global step
+    replayed from a hipGraph (RMHMC_GRAPH, default on) against plain launches: same chains."""
+    M, D, n = 900, 50, 200
+    XX, t = synthetic_logreg(M, D, 9)
+
+    def run(**env):
+        for k in ("RMHMC_CCACHE", "RMHMC_GRAPH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with hip.context(M, D, n, flags=0) as ctx:
+            ctx.set_data(XX, t)
+            ctx.chains_init(seed=4, L=6, eps=0.4, K=4)
+            ctx.chains_run(24)
+            return ctx.chains_state()
+
+    base, nograph, nocache = run(), run(RMHMC_GRAPH="0"), run(RMHMC_CCACHE="0")
+    for a, b in zip(base, nograph):
+        assert np.array_equal(a, b)
+    assert np.array_equal(base[1], nocache[1]) and np.array_equal(base[2], nocache[2])     # same transitions, same accept decisions
+    assert rel_err(base[0], nocache[0]) < 1e-11
