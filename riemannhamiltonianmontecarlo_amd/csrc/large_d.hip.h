@@ -31,7 +31,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_rowpass_big(DevData dd, int n_chains, int nsplit, int nbk, const int* __restrict__ phase,
                                                      const double* __restrict__ wq, double* __restrict__ out0,
                                                      double* __restrict__ out2, double* __restrict__ gpart,
-                                                     double* __restrict__ ljl_part) {
+                                                     double* __restrict__ ljl_part, d4* __restrict__ ctile) {
   constexpr int NB = 4, KK = 16;
   __shared__ double red[2][4][64][4];
   const int DP = dd.DP;
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void k_rowpass_big(DevData dd, int n_chains, i
       for (int r = 0; r < 4; ++r) red[par][w][lane][r] = F[r];
     }
     __syncthreads();
+    d4 cc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double f = 0.0;
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void k_rowpass_big(DevData dd, int n_chains, i
       const double em = exp(-f);
       const double p = 1.0 / (1.0 + em);
       const double v = p * (1.0 - p);
+      cc[r] = v * (1.0 - 2.0 * p);
       const size_t o = (size_t)cj * dd.Mp + n;
       if (MODE == RP_V) {
         if (live && w == 0) out0[o] = v;
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(256) void k_rowpass_big(DevData dd, int n_chains, i
         }
       }
     }
+    // c in the accumulator layout, for k_mompass_big<2> at the same position (as k_rowpass / k_mompass for D <= 64)
+    if (MODE == RP_F && ctile && live && w == 0) ctile[((size_t)blockIdx.x * nb16 + b) * 64 + lane] = cc;
   }
   if (MODE != RP_V) {
     lj = col4_sum(lj);
@@ -118,9 +122,11 @@ __global__ __launch_bounds__(256) void k_rowpass_big(DevData dd, int n_chains, i
   }
 }
 
-// quadratic-term pass (k_mompass), D > 64
+// quadratic-term pass (k_mompass), D > 64.  CM as in k_mompass: 0 c from F, 1 the same and stored (wave 0 writes the tile), 2 c loaded: no
+// F product, no exp, and half the cross-wave reduction.
+template <int CM>
 __global__ __launch_bounds__(256) void k_mompass_big(DevData dd, int n_chains, int nsplit, int nbk, const double* __restrict__ wq,
-                                                     const double* __restrict__ uq, double* __restrict__ qpart) {
+                                                     const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile) {
   constexpr int NB = 4, KK = 16;
   __shared__ double red[2][4][64][8];
   const int DP = dd.DP;
@@ -133,9 +139,10 @@ __global__ __launch_bounds__(256) void k_mompass_big(DevData dd, int n_chains, i
   double Wb[KK], Ub[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    Wb[kk] = act ? wq[(size_t)cj * DP + 64 * w + 4 * kk + rr] : 0.0;
+    Wb[kk] = (act && CM != 2) ? wq[(size_t)cj * DP + 64 * w + 4 * kk + rr] : 0.0;
     Ub[kk] = act ? uq[(size_t)cj * DP + 64 * w + 4 * kk + rr] : 0.0;
   }
+  d4* __restrict__ ct = ctile + (size_t)blockIdx.x * (dd.Mp / 16) * 64 + lane;
   const int nb16 = dd.Mp / 16;
   const int per = (nb16 + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(nb16, b0 + per);
@@ -159,25 +166,30 @@ __global__ __launch_bounds__(256) void k_mompass_big(DevData dd, int n_chains, i
       d4 F = (d4){0.0, 0.0, 0.0, 0.0}, S = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
+        if (CM != 2) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
         S = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Ub[kk], S, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { red[par][w][lane][r] = F[r]; red[par][w][lane][4 + r] = S[r]; }
+      for (int r = 0; r < 4; ++r) { if (CM != 2) red[par][w][lane][r] = F[r]; red[par][w][lane][4 + r] = S[r]; }
     }
+    d4 cc;
+    if (CM == 2 && act) cc = ct[(size_t)b * 64];
     __syncthreads();
     if (act) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double f = 0.0, s = 0.0;
-        for (int ww = 0; ww < nbk; ++ww) { f += red[par][ww][lane][r]; s += red[par][ww][lane][4 + r]; }
-        const double em = exp(-f);
-        const double p = 1.0 / (1.0 + em);
-        const double cn = p * (1.0 - p) * (1.0 - 2.0 * p);
-        const double R = cn * s * s;
+        for (int ww = 0; ww < nbk; ++ww) { if (CM != 2) f += red[par][ww][lane][r]; s += red[par][ww][lane][4 + r]; }
+        if (CM != 2) {
+          const double em = exp(-f);
+          const double p = 1.0 / (1.0 + em);
+          cc[r] = p * (1.0 - p) * (1.0 - 2.0 * p);
+        }
+        const double R = cc[r] * s * s;
 #pragma unroll
         for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], R, Q[I], 0, 0, 0);
       }
+      if (CM == 1 && w == 0) ct[(size_t)b * 64] = cc;
     }
   }
   if (act && c0 + ci < n_chains) {

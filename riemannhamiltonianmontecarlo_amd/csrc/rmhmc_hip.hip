@@ -211,7 +211,7 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
     if (ctx->big) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
       hipLaunchKernelGGL((k_rowpass_big<MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, g.ch.phase, w, out0, out2,
-                         g.ch.gpart, g.ch.ljl_part);
+                         g.ch.gpart, g.ch.ljl_part, g.ctile);
       return;
     }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
@@ -326,13 +326,17 @@ void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
 // cmode (generic path): 1 = first pass at this w, c is computed and kept; 2 = c of this w is at hand (k_mompass in kernels.hip.h)
 void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w, int cmode) {
   launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
+    if (!ctx->ccache) cmode = 0;
     if (ctx->big) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
-      hipLaunchKernelGGL(k_mompass_big, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, w, g.ch.uq, g.ch.qpart);
+      switch (cmode) {
+        case 1: hipLaunchKernelGGL(k_mompass_big<1>, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, w, g.ch.uq, g.ch.qpart, g.ctile); break;
+        case 2: hipLaunchKernelGGL(k_mompass_big<2>, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, w, g.ch.uq, g.ch.qpart, g.ctile); break;
+        default: hipLaunchKernelGGL(k_mompass_big<0>, grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, ctx->nbk, w, g.ch.uq, g.ch.qpart, g.ctile); break;
+      }
       return;
     }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
-    if (!ctx->ccache) cmode = 0;
     switch (cmode) {
       case 1: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 1>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
       case 2: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 2>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
@@ -802,7 +806,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       RC(dalloc(ctx, &g.ch.qpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.gpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.ljl_part, (size_t)g.n * g.nsplit));
-      if (!ctx->big && ctx->ccache) RC(dalloc(ctx, &g.ctile, (size_t)((g.n + 15) / 16) * (ctx->Mp / 16) * 64));
+      if (ctx->ccache) RC(dalloc(ctx, &g.ctile, (size_t)((g.n + 15) / 16) * (ctx->Mp / 16) * 64));
       if (!ctx->big) {
         // fp64 assembly (k_assemble: one chain per wavefront over all M rows): below ~1024 chains the launch has fewer wavefronts than
         // the chip has SIMDs, so the rows are cut until ~2048 wavefronts exist (at least 256 rows per range, at most 16 ranges).
