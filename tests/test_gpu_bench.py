@@ -179,3 +179,18 @@ def test_experiment_driver_on_the_gpu(hip):
     assert np.array_equal(a["ESS"], tools.CalculateESS(a["results_beta"].mean(axis=0), 199))
     assert a["Time per Min ESS"] == round(a["avg_time_taken"] / a["ESS"].min(), 6)
     assert 20 < a["per_run"]["Min"] <= 200            # RMHMC on heart: nearly independent samples (paper Table 6: 4862 of 5000)
+
+
+def test_hmc_shim_prints_like_the_reference(hip, capsys):
+    """hmc.py:85-97: after iterations 0, 50, ... up to BurnIn '<number> iterations completed.' and the acceptance rate of the window, the
+    burn-in banner after iteration BurnIn, the time at the end."""
+    from riemannhamiltonianmontecarlo_amd import HMC
+    XX, t = synthetic_logreg(300, 6, 1)
+    capsys.readouterr()
+    w, secs = HMC(XX, t, NumOfIterations=130, BurnIn=60, NumOfLeapFrogSteps=20, StepSize=0.05, seed=2)
+    out = capsys.readouterr().out.splitlines()
+    assert w.shape == (70, 6) and secs > 0
+    assert out[0] == "0 iterations completed." and out[1] in ("Acceptance: 1.0", "Acceptance: 0.0")
+    assert out[2] == "50 iterations completed." and out[3].startswith("Acceptance: ") and 0.0 <= float(out[3].split()[1]) <= 1.0
+    assert out[4] == "Burn-in complete, now drawing posterior samples."
+    assert len(out) == 6 and out[5].startswith("Time drawing posterior: ")
