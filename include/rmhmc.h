@@ -233,13 +233,21 @@ int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t 
                        double *seconds_out);
 
 /* Progress reports of the bulk samplers (rmhmc_sample*, rmhmc_hmc_sample).  The reference prints the iteration count and the
- * acceptance rate of the last window whenever IterationNum+1 is a multiple of 50 (rmhmc.py:38-45, hmc.py:32-38) and a banner
- * when burn-in completes (rmhmc.py:194-196).  With a callback set, fn(RMHMC_EV_PROGRESS, m, accepted, user) is called from the
- * calling thread each time EVERY chain has completed exactly m = first, first+every, first+2 every, ... transitions (accepted =
- * accepted proposals summed over all chains so far), and fn(RMHMC_EV_BURNIN_DONE, burn_in+1, accepted, user) when the burn-in
- * phase ends, just before the TimeTaken timer starts.  Samples do not depend on it.  fn = NULL switches the reports off.
- * The oracle accepts the call and never reports.                                                                          */
-typedef void (*rmhmc_progress_fn)(int32_t event, int64_t iterations_done, int64_t accepted_total, void *user);
+ * acceptance rate of the last window whenever IterationNum+1 is a multiple of 50 (rmhmc.py:38-45; hmc.py:85-89) and a banner
+ * when burn-in completes (rmhmc.py:194-196).  With a callback set, fn(RMHMC_EV_PROGRESS, m, accepted, iterations, user) is
+ * called from the calling thread for the milestones m = first, first+every, first+2 every, ...; accepted / iterations =
+ * accepted proposals / completed transitions summed over all chains at that moment (the window's acceptance rate is the ratio
+ * of their increments between two reports).
+ *   One chain: the run is cut at every milestone, so the report comes exactly when m transitions are complete, as the
+ *   reference prints it.
+ *   Several chains: nobody is stopped; the report for m comes at the first host synchronisation after the SLOWEST chain has
+ *   completed m transitions (the others are ahead, iterations > n m), and milestones passed since the last report are merged
+ *   into one call with the largest of them.
+ * fn(RMHMC_EV_BURNIN_DONE, burn_in+1, accepted, iterations, user) is called when the burn-in phase ends (every chain at exactly
+ * burn_in+1 transitions), just before the TimeTaken timer starts.  Samples do not depend on any of it.  fn = NULL switches the
+ * reports off.  The oracle accepts the call and never reports.                                                            */
+typedef void (*rmhmc_progress_fn)(int32_t event, int64_t iterations_done, int64_t accepted_total, int64_t iterations_total,
+                                  void *user);
 #define RMHMC_EV_PROGRESS 0
 #define RMHMC_EV_BURNIN_DONE 1
 int rmhmc_set_progress(rmhmc_ctx *ctx, rmhmc_progress_fn fn, int64_t first, int64_t every, void *user);

@@ -54,7 +54,7 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
 
-PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int64, C.c_int64, C.c_void_p)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
 EV_PROGRESS, EV_BURNIN_DONE = 0, 1
 
 # every symbol include/rmhmc.h declares, with its signature
@@ -356,13 +356,14 @@ class Context:
         self._ck(self.lib.rmhmc_chains_restore(self._h, _ptr(it, _lp), _ptr(acc, _lp)))
 
     def set_progress(self, fn, first=49, every=50):
-        """fn(event, iterations_done, accepted_total) or None.  The defaults are the reference's schedule: a report whenever
-        IterationNum+1 is a multiple of 50, i.e. after 49, 99, ... completed transitions (rmhmc.py:38)."""
+        """fn(event, iterations_done, accepted_total, iterations_total) or None.  The defaults are the reference's schedule: a report
+        whenever IterationNum+1 is a multiple of 50, i.e. after 49, 99, ... completed transitions (rmhmc.py:38).  One chain: exactly
+        then; several chains: when the slowest chain has got there (include/rmhmc.h)."""
         if fn is None:
             self._progress_cb = PROGRESS_FN(0)
             self._ck(self.lib.rmhmc_set_progress(self._h, self._progress_cb, 1, 1, None))
             return
-        self._progress_cb = PROGRESS_FN(lambda ev, it, acc, user: fn(int(ev), int(it), int(acc)))   # kept alive with the context
+        self._progress_cb = PROGRESS_FN(lambda ev, it, acc, itot, user: fn(int(ev), int(it), int(acc), int(itot)))   # kept alive with the context
         self._ck(self.lib.rmhmc_set_progress(self._h, self._progress_cb, int(first), int(every), None))
 
     def int8_certificate(self):

@@ -115,7 +115,7 @@ struct rmhmc_ctx {
   // progress reports of the bulk samplers (rmhmc_set_progress)
   rmhmc_progress_fn progress_fn = nullptr;
   void* progress_user = nullptr;
-  long long progress_first = 0, progress_every = 0;
+  long long progress_first = 0, progress_every = 0, progress_next = 0;
   // timing
   bool timing = false;
   std::map<std::string, std::vector<EvPair>> events;
@@ -1254,6 +1254,31 @@ static int poll_progress(rmhmc_ctx* ctx, int* done, long long* min_iter) {
   return RMHMC_OK;
 }
 
+// rmhmc_set_progress: hand the caller the counters at a moment when every chain has completed at least `iters` transitions
+static int report_progress(rmhmc_ctx* ctx, int event, long long iters) {
+  std::vector<long long> acc(ctx->n), it(ctx->n);
+  RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
+  RC(download(ctx, it.data(), ctx->ch.iter, ctx->n));
+  RC(sync(ctx));
+  long long tot = 0, tit = 0;
+  for (long long a : acc) tot += a;
+  for (long long a : it) tit += a;
+  ctx->progress_fn(event, iters, tot, tit, ctx->progress_user);
+  return RMHMC_OK;
+}
+// Batches of several chains report without stopping anybody: whenever the host looks at the device anyway, the milestones the
+// SLOWEST chain has passed since the last report are reported (once, with the largest of them).  Cutting a batch at every
+// milestone, as the one-chain mode does to reproduce the reference's print-out exactly, would make every chain wait for the
+// slowest fifty iterations at a time (+27 % at 8192 chains).
+static bool progress_ticking(const rmhmc_ctx* ctx) { return ctx->progress_fn && ctx->progress_every > 0 && ctx->n > 1; }
+static int progress_fire(rmhmc_ctx* ctx, long long min_iter) {
+  if (!progress_ticking(ctx)) return RMHMC_OK;
+  long long last = -1;
+  while (ctx->progress_next <= min_iter) { last = ctx->progress_next; ctx->progress_next += ctx->progress_every; }
+  if (last >= 0) RC(report_progress(ctx, RMHMC_EV_PROGRESS, last));
+  return RMHMC_OK;
+}
+
 static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_steps) {
   // Every chain needs at least min_steps more global steps.  Afterwards the host looks at the device state and issues, each time,
   // as many steps as the slowest chain is certain to need: (limit - its completed transitions), a transition taking >= 1 step.
@@ -1263,18 +1288,28 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
   long long s = min_steps, min_iter = 0;
   const long long poll = 4;
   const bool fused = ctx->fused && ctx->sampler == 0;
+  const bool ticking = progress_ticking(ctx);
+  const long long chunk = ticking ? std::max<long long>(8, ctx->progress_every * (ctx->L + 1) / 2) : min_steps;  // ~ one report per chunk
   StepGraph sg;
   fork_streams(ctx);
-  if (fused) {
-    launch_fused(ctx, ib, min_steps);
-  } else {
-    if (step_graph_usable(ctx, min_steps)) (void)build_step_graph(ctx, ib, sg);
-    run_generic_steps(ctx, ib, min_steps, &sg);
+  if (!fused && step_graph_usable(ctx, std::min(min_steps, chunk))) (void)build_step_graph(ctx, ib, sg);
+  for (long long left = min_steps; left > 0;) {
+    const long long k = std::min(left, chunk);
+    if (fused) launch_fused(ctx, ib, k);
+    else run_generic_steps(ctx, ib, k, &sg);
+    left -= k;
+    if (ticking && left > 0) {
+      RC(poll_progress(ctx, &done, &min_iter));
+      RC(progress_fire(ctx, min_iter));
+      fork_streams(ctx);
+    }
   }
   for (;;) {
     RC(poll_progress(ctx, &done, &min_iter));
+    RC(progress_fire(ctx, min_iter));
     if (done >= ctx->n) break;
-    const long long next = std::max(poll, ib.limit - min_iter);
+    long long next = std::max(poll, ib.limit - min_iter);
+    if (ticking) next = std::min(next, chunk);
     fork_streams(ctx);
     if (fused) launch_fused(ctx, ib, next);
     else run_generic_steps(ctx, ib, next, &sg);
@@ -1284,21 +1319,11 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
   return RMHMC_OK;
 }
 
-// rmhmc_set_progress: tell the caller that every chain has completed `iters` transitions
-static int report_progress(rmhmc_ctx* ctx, int event, long long iters) {
-  std::vector<long long> acc(ctx->n);
-  RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
-  RC(sync(ctx));
-  long long tot = 0;
-  for (long long a : acc) tot += a;
-  ctx->progress_fn(event, iters, tot, ctx->progress_user);
-  return RMHMC_OK;
-}
-// Every chain from exactly `from` to exactly ib.limit completed transitions.  With a progress callback the run is cut at the
-// milestones first, first+every, ...: all chains stop there (those that arrive first wait, as at the burn-in mark), the callback
-// gets the exact counters, and the run goes on; the results do not depend on it (the randomness is keyed by chain and iteration).
+// Every chain from exactly `from` to exactly ib.limit completed transitions.  With a progress callback and ONE chain the run is cut
+// at the milestones first, first+every, ...: the callback gets the exact counters there, as the reference prints them, and the run goes
+// on; the results do not depend on it (the randomness is keyed by chain and iteration).  Several chains: see progress_fire.
 static int run_phase(rmhmc_ctx* ctx, const IterBase& ib, long long from) {
-  if (ctx->progress_fn && ctx->progress_every > 0) {
+  if (ctx->progress_fn && ctx->progress_every > 0 && ctx->n == 1) {
     long long m = ctx->progress_first;
     if (from >= m) m += ((from - m) / ctx->progress_every + 1) * ctx->progress_every;
     for (; m < ib.limit; m += ctx->progress_every) {
@@ -1337,11 +1362,20 @@ static void launch_global_step_prefix(rmhmc_ctx* ctx, const IterBase& ib, int na
 static int run_sorted_phase(rmhmc_ctx* ctx, const IterBase& ib, const std::vector<long long>& T /* descending */) {
   const int n = (int)ctx->n;
   const long long Tmin = T[n - 1], Tmax = T[0];
+  const bool ticking = progress_ticking(ctx);
+  const long long chunk = ticking ? std::max<long long>(8, ctx->progress_every * (ctx->L + 1) / 2) : Tmax + 1;
+  int done = 0;
+  long long mi = 0;
   fork_streams(ctx);
   {
     StepGraph sg;
-    if (step_graph_usable(ctx, Tmin)) (void)build_step_graph(ctx, ib, sg);
-    run_generic_steps(ctx, ib, Tmin, &sg);
+    if (step_graph_usable(ctx, std::min(Tmin, chunk))) (void)build_step_graph(ctx, ib, sg);
+    for (long long left = Tmin; left > 0;) {
+      const long long k = std::min(left, chunk);
+      run_generic_steps(ctx, ib, k, &sg);
+      left -= k;
+      if (ticking) { RC(poll_progress(ctx, &done, &mi)); RC(progress_fire(ctx, mi)); fork_streams(ctx); }
+    }
     HIPCK(hipStreamSynchronize(ctx->stream));  // (the graph goes out of scope)
   }
   int na = n;
@@ -1350,11 +1384,10 @@ static int run_sorted_phase(rmhmc_ctx* ctx, const IterBase& ib, const std::vecto
     const int nar = std::min(n, (na + 127) / 128 * 128);
     if (nar == n) launch_global_step(ctx, ib);
     else launch_global_step_prefix(ctx, ib, nar);
+    if (ticking && (s - Tmin) % chunk == chunk - 1) { RC(poll_progress(ctx, &done, &mi)); RC(progress_fire(ctx, mi)); fork_streams(ctx); }
   }
-  join_streams(ctx);
-  int done = 0;
-  long long mi = 0;
   RC(poll_progress(ctx, &done, &mi));
+  RC(progress_fire(ctx, mi));
   if (done < n) RC(run_until_done(ctx, ib, 1));  // (safety net: never taken if the schedule above is right)
   return RMHMC_OK;
 }
@@ -1364,11 +1397,11 @@ static int run_sorted_phase(rmhmc_ctx* ctx, const IterBase& ib, const std::vecto
 static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const double* theta0, double* d_samples, double* seconds_out) {
   const long long S = n_iter - burn_in;
   const int n = (int)ctx->n;
-  // work-sorted layout (see run_sorted_phase): generic and one-launch stepping paths of the RMHMC sampler, one chain group, no
-  // progress reports (they cut the run at fixed iteration counts)
+  // work-sorted layout (see run_sorted_phase): generic and one-launch stepping paths of the RMHMC sampler, one chain group
   std::vector<long long> T;
   std::vector<double> th_perm;
-  bool sorted = ctx->sampler == 0 && ctx->groups.size() == 1 && !ctx->fused && !ctx->progress_fn && n >= 2 && n_iter > burn_in + 1;
+  bool sorted = ctx->sampler == 0 && ctx->groups.size() == 1 && !ctx->fused && n >= 2 && n_iter > burn_in + 1;
+  ctx->progress_next = ctx->progress_first;
   if (const char* e = getenv("RMHMC_SORTED")) sorted = sorted && atoi(e) != 0;
   if (sorted) {
     hipLaunchKernelGGL(k_traj_steps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)ctx->seed,
@@ -1596,6 +1629,7 @@ int rmhmc_hmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L,
   double* d_samples = nullptr;
   HIPCK(hipMalloc((void**)&d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D));
   ctx->sampler = 1;  // (after the allocation: an early return above must not leave the context in HMC mode)
+  ctx->progress_next = ctx->progress_first;
   int rc = [&]() -> int {
     RC(hmc_init_chains(ctx, theta0));
     const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};

@@ -39,17 +39,18 @@ def progress_printer(n_chains, hmc_burn_in=None):
     multiple of 50 - i.e. after 49, 99, ... completed transitions - the text '<number+1> iterations completed.' and the acceptance
     rate of the window since the last report (the first window holds 49 proposals), plus the burn-in banner.  hmc.py:85-89,92-94
     (hmc_burn_in given): after iterations 0, 50, 100, ... up to BurnIn, '<number> iterations completed.' and the window's rate."""
-    last = {"it": 0, "acc": 0}
+    last = {"itot": 0, "acc": 0}
 
-    def report(event, iters, accepted):
+    def report(event, iters, accepted, iters_total):
         if event == _capi.EV_BURNIN_DONE:
             print('Burn-in complete, now drawing posterior samples.')
             return
         if hmc_burn_in is not None and iters - 1 > hmc_burn_in:
             return
         print('{} iterations completed.'.format(iters + 1 if hmc_burn_in is None else iters - 1))
-        print('Acceptance: {}'.format((accepted - last["acc"]) / float((iters - last["it"]) * n_chains)))
-        last["it"], last["acc"] = iters, accepted
+        # accepted / proposed since the last report, over all chains (one chain: exactly the reference's window)
+        print('Acceptance: {}'.format((accepted - last["acc"]) / float(max(1, iters_total - last["itot"]))))
+        last["itot"], last["acc"] = iters_total, accepted
     return report
 
 

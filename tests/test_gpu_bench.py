@@ -94,16 +94,24 @@ def test_progress_reports_follow_the_reference_schedule(hip, capsys, shape):
     events = []
     with hip.context(M, D, n, flags=_capi.COMPAT) as ctx:
         ctx.set_data(XX, t)
-        ctx.set_progress(lambda ev, it, acc: events.append((ev, it, acc)))
+        ctx.set_progress(lambda ev, it, acc, itot: events.append((ev, it, acc, itot)))
         a = ctx.sample(230, 120, 6, 0.5, 4, seed=3)
         ctx.set_progress(None)
         b = ctx.sample(230, 120, 6, 0.5, 4, seed=3)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    assert [e[1] for e in events if e[0] == _capi.EV_PROGRESS] == [49, 99, 149, 199]
     assert [e[1] for e in events if e[0] == _capi.EV_BURNIN_DONE] == [121]
-    assert [e[1] for e in events] == [49, 99, 121, 149, 199]                      # banner between the reports, where the reference prints it
+    assert [e[3] for e in events if e[0] == _capi.EV_BURNIN_DONE] == [121 * n]         # every chain at exactly BurnIn + 1 transitions
+    prog = [e for e in events if e[0] == _capi.EV_PROGRESS]
+    if n == 1:   # one chain: cut at every milestone, exact counters, banner between the reports where the reference prints it
+        assert [e[1] for e in prog] == [49, 99, 149, 199] and [e[3] for e in prog] == [49, 99, 149, 199]
+        assert [e[1] for e in events] == [49, 99, 121, 149, 199]
+    else:        # several chains: nobody waits; a report names the largest milestone the slowest chain has passed
+        ms = [e[1] for e in prog]
+        assert ms == sorted(set(ms)) and set(ms) <= {49, 99, 149, 199} and ms[-1] == 199
+        assert all(e[3] >= n * e[1] for e in prog)                                     # the other chains are ahead
     accs = [e[2] for e in events]
-    assert accs == sorted(accs) and accs[-1] <= a[1].sum() <= 230 * n             # accepted-so-far is monotone and consistent with the total
+    assert accs == sorted(accs) and accs[-1] <= a[1].sum() <= 230 * n                 # accepted-so-far is monotone and consistent with the total
+    assert all(e[2] <= e[3] for e in events)
     if n == 1:
         capsys.readouterr()
         RMHMC(XX, t, NumOfIterations=230, BurnIn=120, seed=3)
