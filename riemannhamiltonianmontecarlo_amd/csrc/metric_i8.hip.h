@@ -39,6 +39,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i16v __attribute__((ext_vector_type(16)));
@@ -103,6 +104,30 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Hand-placed fragment reads and waits (I8_ASMFRAG, the TN = 1 forms).  The compiler closes the fragment reads of a stage with one
+// s_waitcnt lgkmcnt(0) before the first MFMA - ten ds_read_b128 (the next group's A fragments included) where that MFMA needs three -
+// and with eight waves starting a stage together after the barrier the whole workgroup's 80 KB of reads are serialised in front of the
+// first matrix instruction.  Here the reads are inline assembly (the compiler does not track them) and every MFMA pair is preceded by
+// the counted wait for exactly its operands; ds_read results return in issue order.  The waits name their fragments as in/out
+// operands so that the MFMAs using them cannot be scheduled above the wait.
+template <int OFF>
+__device__ __forceinline__ i4v lds_read_b128(unsigned addr) {
+  i4v r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm(i4v& a, i4v& b, i4v& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm(i4v& a, i4v& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+#ifndef I8_ASMFRAG
+#define I8_ASMFRAG 1
+#endif
+
 // I8_ABLATE (tools/i8_gemm_probe.hip only; the library never defines it): bit 0 no LDS-DMA loads, bit 1 no fragment reads (the
 // fragments of the first stage are kept), bit 2 no barriers.  Timing ablations: the results are meaningless.
 #ifndef I8_ABLATE
@@ -120,8 +145,12 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   const int wm = wave & 1, wn = wave >> 1;
   // nks stages starting at the given pointers; nks_total = stages per slice plane (a launch may cover part of the k range)
   const size_t strideV = (size_t)nks_total * nCp * 32, strideZ = (size_t)nks_total * NPp * 32;
-  const int8_t* gsrc[NU];
+  // A wave's 64 units of a stage lie all in the A (chain) part or all in the B part, so the operand base, the stage step and the slice
+  // stride are wave uniform (SGPRs) and only the unit's offset inside the tile is per lane: the loads take the scalar-base form,
+  // one 32-bit VGPR of address per unit instead of 64-bit pointer arithmetic in the loop.
+  const int8_t* gbase[NU];
   size_t gstep[NU], gslice[NU];
+  unsigned goff[NU];
   int lbase[NU];  // wave-uniform LDS byte offset of the wave's 64 units
   bool on[NU];
   int n_on = 0;
@@ -130,20 +159,30 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
     const int u = t + k * NT;
     on[k] = (u & ~63) < 2 * ROWS;  // wave-uniform
     n_on += on[k] ? 1 : 0;
-    const bool isA = u < 2 * BM;
+    const bool isA = __builtin_amdgcn_readfirstlane((int)((u & ~63) < 2 * BM)) != 0;  // wave-uniform
     const int row = u >> 1, half = (u & 1) ^ ((row >> 3) & 1);  // the unit stored at LDS slot u holds this logical half
     const int lrow = isA ? row : row - BM;
-    gsrc[k] = (isA ? Vs + ((size_t)cb * BM) * 32 : Zs + ((size_t)pb * BN) * 32) + (size_t)lrow * 32 + half * 16;
+    gbase[k] = isA ? Vs + ((size_t)cb * BM) * 32 : Zs + ((size_t)pb * BN) * 32;
+    goff[k] = (unsigned)(lrow * 32 + half * 16);
     gstep[k] = isA ? (size_t)nCp * 32 : (size_t)NPp * 32;
     gslice[k] = isA ? strideV : strideZ;
     lbase[k] = __builtin_amdgcn_readfirstlane((u & ~63) * 16);
   }
+  // ALLON: every thread owns exactly one 16-byte unit of the stage (the 8-wave form: 2 ROWS = 512 units = 512 threads).  Then the loads
+  // are issued UNCONDITIONALLY - in the last two stages of the tile, which have nothing left to prefetch, the last stage is fetched again
+  // into a buffer nobody reads any more - so that a stage of the main loop is one basic block: with the conditional issue the
+  // compiler closed every product group with s_waitcnt lgkmcnt(0), i.e. the first MFMA of a stage waited for all ten fragment
+  // reads instead of the two it needs.
+#ifndef I8_ALLON
+#define I8_ALLON 1
+#endif
+  constexpr bool ALLON = I8_ALLON && (NU == 1) && (2 * ROWS == NT);
   auto gl1 = [&](int ks, int buf, int s) {  // slice s of stage ks
     if (I8_ABLATE & 1) return;
 #pragma unroll
     for (int k = 0; k < NU; ++k)
-      if (on[k])
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gsrc[k] + s * gslice[k] + (size_t)ks * gstep[k]),
+      if (ALLON || on[k])
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gbase[k] + (s * gslice[k] + (size_t)ks * gstep[k]) + goff[k]),
                                          (lds_ptr_t)(lds + buf * STAGE + s * ROWS * I8_ROWB + lbase[k]), 16, 0, 0);
   };
   auto gl = [&](int ks, int buf) {
@@ -178,12 +217,39 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   for (int ks = 0; ks < nks; ++ks) {
     const int nxt = cur == 2 ? 0 : cur + 1, wr = nxt == 2 ? 0 : nxt + 1;
     const bool spread = I8_DSPREAD && (WN != 4 || work);  // (waves that skip their MFMAs issue their loads at the top)
-    if (!spread && ks + 2 < nks) gl(ks + 2, wr);
+    const int kpre = ALLON ? min(ks + 2, nks - 1) : ks + 2;  // stage to prefetch (ALLON: clamped, always issued)
+    if (!spread && (ALLON || ks + 2 < nks)) gl(kpre, wr);
     const unsigned char* bc = lds + ((I8_ABLATE & 2) ? 0 : cur) * STAGE;
     if (WN != 4 || work) {
     const bool rd = !(I8_ABLATE & 2) || ks == 0;
+    if (I8_ASMFRAG && TN == 1 && !(I8_ABLATE & 2)) {
+      // read order: A_0 (2), B_{S-1} .. B_0 (S), A_1 (2); group i >= 1 issues A_{i+1} first.  Outstanding reads before the MFMA pair
+      // (0, j): the ones issued after B_j, i.e. j + 2; before group i >= 1: the two of A_{i+1} (none for the last group).
+      const unsigned aA = (unsigned)(size_t)(lds_ptr_t)(lds) + cur * STAGE + fragA, aB = (unsigned)(size_t)(lds_ptr_t)(lds) + cur * STAGE + fragB;
+      fa[0][0] = lds_read_b128<0>(aA);
+      fa[0][1] = lds_read_b128<32 * I8_ROWB>(aA);
+      [&]<int... J>(std::integer_sequence<int, J...>) { ((fb[S - 1 - J][0] = lds_read_b128<(S - 1 - J) * ROWS * I8_ROWB>(aB)), ...); }(std::make_integer_sequence<int, S>{});
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ([&] {
+          constexpr int i = I;
+          if constexpr (i + 1 < S) {
+            fa[(i + 1) & 1][0] = lds_read_b128<(i + 1) * ROWS * I8_ROWB>(aA);
+            fa[(i + 1) & 1][1] = lds_read_b128<(i + 1) * ROWS * I8_ROWB + 32 * I8_ROWB>(aA);
+          }
+          if (spread && (ALLON || ks + 2 < nks)) gl1(kpre, wr, i);
+          if constexpr (i > 0) wait_lgkm<(i + 1 < S) ? 2 : 0>(fa[i & 1][0], fa[i & 1][1]);
+          [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
+            ([&] {
+              constexpr int j = S - 1 - i - JJ;
+              if constexpr (i == 0) wait_lgkm<j + 2>(fa[0][0], fa[0][1], fb[j][0]);
+              acc[i + j][0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][0], fb[j][0], acc[i + j][0][0], 0, 0, 0);
+              acc[i + j][1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][1], fb[j][0], acc[i + j][1][0], 0, 0, 0);
+            }(), ...);
+          }(std::make_integer_sequence<int, S - i>{});
+        }(), ...);
+      }(std::make_integer_sequence<int, S>{});
+    } else {
     // issue order pinned (sched_barrier) so that the fragments of product group i+1 are in flight while group i is multiplied
-    // and the compiler's counted lgkmcnt waits retire only what the next MFMA needs
     if (rd) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) fa[0][a] = *(const i4v*)(bc + fragA + a * 32 * I8_ROWB);
@@ -198,7 +264,7 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
 #pragma unroll
         for (int a = 0; a < 2; ++a) fa[(i + 1) & 1][a] = *(const i4v*)(bc + (i + 1) * ROWS * I8_ROWB + fragA + a * 32 * I8_ROWB);
       }
-      if (spread && ks + 2 < nks) gl1(ks + 2, wr, i);
+      if (spread && (ALLON || ks + 2 < nks)) gl1(kpre, wr, i);
       if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = S - 1 - i; j >= 0; --j) {
@@ -212,10 +278,12 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
       if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
     }
-    if (ks + 2 < nks) retire_older(); else wait_vmcnt<0>();
+    }
+    if (ALLON || ks + 2 < nks) retire_older(); else wait_vmcnt<0>();
     if (!(I8_ABLATE & 4)) __builtin_amdgcn_s_barrier();
     cur = nxt;
   }
+  if (ALLON) wait_vmcnt<0>();  // (the re-fetches of the last two stages: no LDS-DMA write may outlive the workgroup)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
