@@ -4,7 +4,7 @@
 // v_mfma_i32_32x32x32_i8, one accumulator set per weight g = i+j, and combined in fp64 at the end.
 // Checks the kernel against a CPU loop on a small case with asymmetric data, then times it at the config-3 shape
 // (8192 chains x 2080 column pairs x 10000 data rows).
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/i8_gemm_probe tools/i8_gemm_probe.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -mllvm -amdgpu-mfma-vgpr-form=1 -o tools/i8_gemm_probe tools/i8_gemm_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
