@@ -190,11 +190,18 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
   d4 Gr[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Gr[I] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int b = b0; b < b1; ++b) {
-    const int n0 = b * 16;
-    double A[KK];
+  // Software pipeline as in k_mompass: the A operand of the next tile's F product is requested before the matrix instructions of the
+  // current tile (two register sets), the A operand of the gradient product at the start of its own tile.  Not for the variant that
+  // also cuts v into byte slices (I8): there the extra live registers cost more than the exposed latency (rowpass 2.73 -> 2.90 ms per
+  // step with the pipeline, against 2.33 -> 2.06 for the fp64 variants), so it keeps the compiler's own schedule at 5 waves per SIMD.
+  constexpr bool PIPE = !I8;
+  double A0[KK], A1[KK];
+  auto load_a = [&](double (&A)[KK], int b) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + n0];
+    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + b * 16];
+  };
+  auto tile = [&](const double (&A)[KK], int b) {
+    const int n0 = b * 16;
     double xb[4][NB];
     if (MODE != RP_V) {
 #pragma unroll
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
 #pragma unroll
         for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + 4 * r) * DP + I];
     }
+    if (PIPE) __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above the products below)
     d4 F = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
@@ -297,6 +305,22 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
           if (st) *(unsigned*)(vs.Vs + (((size_t)(vs.S - 1 - j) * vs.nks + ks) * vs.nCp + cj) * 32 + (n0 & 31) + 4 * rr) = tq;
         }
       }
+    }
+  };
+  if (PIPE) {
+    if (b0 < b1) load_a(A0, b0);
+    for (int b = b0; b < b1; b += 2) {
+      if (b + 1 < b1) load_a(A1, b + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      tile(A0, b);
+      if (b + 2 < b1) load_a(A0, b + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (b + 1 < b1) tile(A1, b + 1);
+    }
+  } else {
+    for (int b = b0; b < b1; ++b) {
+      load_a(A0, b);
+      tile(A0, b);
     }
   }
   if (I8 && MODE != RP_G && bad && live) atomicOr(&vs.vbad[cj], 1);
@@ -512,18 +536,24 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
   for (int I = 0; I < NB; ++I) Q[I] = (d4){0.0, 0.0, 0.0, 0.0};
   const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + ci;     // A of F,S: X[n0+ci][4kk+rr]
   const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;   // A of Q  : X[n0+4r+rr][NB*ci+I]
-  for (int b = b0; b < b1; ++b) {
-    const int n0 = b * 16;
-    d4 cc;
-    if (CM == 2) cc = ct[(size_t)b * 64];
-    double A[KK];
+  // Software pipeline over the 16-row tiles: the A operand of F / S (and c) of the NEXT tile is requested before the matrix instructions
+  // of the current one, and the A operand of Q of the current tile at its start, behind the F / S products.  Left to itself the
+  // compiler keeps two A registers in flight and puts an s_waitcnt vmcnt(1) in front of every MFMA: a wave then pays the L2 latency
+  // sixteen times per tile and only the four waves per SIMD hide some of it (59 % MFMA busy).
+  double A0[KK], A1[KK];
+  d4 cc0, cc1;
+  auto load_a = [&](double (&A)[KK], d4& cc, int b) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + n0];
+    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + b * 16];
+    if (CM == 2) cc = ct[(size_t)b * 64];
+  };
+  auto tile = [&](const double (&A)[KK], d4 cc, int b) {
     double xb[4][NB];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + 4 * r) * DP + I];
+      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(b * 16 + 4 * r) * DP + I];
+    __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above the products below)
     d4 F = (d4){0.0, 0.0, 0.0, 0.0}, S = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -545,6 +575,15 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
 #pragma unroll
       for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], R, Q[I], 0, 0, 0);
     }
+  };
+  if (b0 < b1) load_a(A0, cc0, b0);
+  for (int b = b0; b < b1; b += 2) {
+    if (b + 1 < b1) load_a(A1, cc1, b + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    tile(A0, cc0, b);
+    if (b + 2 < b1) load_a(A0, cc0, b + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (b + 1 < b1) tile(A1, cc1, b + 1);
   }
   if (c0 + ci < n_chains) {
     double* __restrict__ out = qpart + ((size_t)split * n_chains + c0 + ci) * DP;
