@@ -39,8 +39,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md (spec; 6.3e12 achievable, 5.94e12 measured by tools/mfma_probe)
 INT8_MFMA_PEAK = 5.0e15   # op/s dense int8 matrix (2x the bf16 rate, MI355X_MICROARCH.md)
-INT8_MFMA_STREAM = 2.85e15  # op/s a bare v_mfma_i32_32x32x32_i8 stream sustains on random bytes (power limited: 1.70 GHz at 80 % pipe
-                            # occupancy, profiles/r01_i8_gemm_probe.txt)
+INT8_MFMA_STREAM = 3.39e15  # op/s a bare v_mfma_i32_32x32x32_i8 stream sustains on random bytes with two waves per SIMD (2.89e15 with one; 5.04e15
+                            # on zeros: the clock is given back under load; profiles/r02_i8_stream_probe.txt)
 FP64_MFMA_PEAK = 78.6e12  # flop/s dense fp64 matrix (spec); tools/mfma_probe measures 75.1e12
 
 WORKLOADS = {
