@@ -133,7 +133,18 @@ __device__ __forceinline__ void wait_lgkm(i4v& a, i4v& b) {
 #ifndef I8_ABLATE
 #define I8_ABLATE 0
 #endif
-template <int S, int WN, int TN, int PIN, class Epilogue>
+// sum_g acc_g 2^(-8g) in fp64 (Horner from the least significant weight): the ONE place where the integer sums become a double, so
+// that every route to a G entry (one launch, k pieces summed as integers, the left-over pair blocks) rounds alike
+template <int S, class F>
+__device__ __forceinline__ double i8_combine(F&& acc_of) {
+  double val = 0.0;
+#pragma unroll
+  for (int g = S - 1; g >= 0; --g) val = val * 0.00390625 + (double)acc_of(g);
+  return val;
+}
+
+// RAW: the epilogue gets the int32 accumulators themselves, epi(row, col, g, acc_g), instead of their fp64 combination.
+template <int S, int WN, int TN, int PIN, bool RAW = false, class Epilogue>
 __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks_total, int nks,
                                              int cb, int pb, int rows_real, int cols_real, Epilogue&& epi) {
   constexpr int BM = I8_BM, BN = 32 * TN * WN, ROWS = BM + BN, NT = 128 * WN;
@@ -290,12 +301,14 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        double val = 0.0;
-#pragma unroll
-        for (int g = S - 1; g >= 0; --g) val = val * 0.00390625 + (double)acc[g][a][b][r];
         const int row = cb * BM + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int col = pb * BN + wn * 32 * TN + b * 32 + (lane & 31);
-        epi(row, col, val);
+        if constexpr (RAW) {
+#pragma unroll
+          for (int g = 0; g < S; ++g) epi(row, col, g, acc[g][a][b][r]);
+        } else {
+          epi(row, col, i8_combine<S>([&](int g) { return acc[g][a][b][r]; }));
+        }
       }
 }
 
@@ -304,12 +317,16 @@ constexpr int i8_lds_bytes() { return 3 * S * (I8_BM + 32 * TN * WN) * I8_ROWB; 
 
 // probe / unit-test form (tools/i8_gemm_probe.hip): C[row][col] = sum_g acc_g 2^(-8g)
 template <int S, int WN, int TN, int PIN>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_gemm_i8_probe(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN >= 2 ? WN / 2 : 1, WN >= 2 ? WN / 2 : 1))) void k_gemm_i8_probe(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
                                                             int nC, int NP, double* __restrict__ C) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NPp / (32 * TN * WN), cb, pb)) return;
   gemm_i8_tile<S, WN, TN, PIN>(Vs, Zs, nCp, NPp, nks, nks, cb, pb, nC - cb * I8_BM, NP - pb * 32 * TN * WN,
-                          [&](int row, int col, double val) { C[(size_t)row * NPp + col] = val; });
+                          [&](int row, int col, double val) {
+#ifdef I8_PROBE_NOSTORE  // (timing only: the epilogue's conversions stay, its stores go)
+                            if (val == 1.2345e300)
+#endif
+                            C[(size_t)row * NPp + col] = val; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,9 +491,9 @@ template <int S, int WN, int TN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
                                                           int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
                                                           const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
-                                                          size_t plane_stride, const int* __restrict__ vexp) {
-  int cb, pb;
-  if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, pr.NPp / (32 * TN * WN), cb, pb)) return;
+                                                          size_t plane_stride, const int* __restrict__ vexp, int npb) {
+  int cb, pb;  // npb: pair blocks of this launch (all of them, or the full ones when k_assemble_i8_tail takes the ragged rest)
+  if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, npb, cb, pb)) return;
   // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow.
   // gridDim.y > 1 (small batches, too few tiles to fill the chip): the k range is cut into gridDim.y pieces, piece y writes plane y of
   // Gq (plane_stride apart) and k_sum_planes adds the planes up in a fixed order.
@@ -484,18 +501,95 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
   const int kb = ks0 + (int)blockIdx.y * per, kn = min(per, ks0 + nk - kb);
   double* __restrict__ Gout = Gq + (size_t)blockIdx.y * plane_stride;
   const bool first = blockIdx.y == 0;
+  // What the epilogue needs per chain and per pair of the tile goes to LDS up front, one element per thread and all loads of the
+  // workgroup in flight together: read inside the epilogue they were dependent loads (phase -> branch -> scale, ...) that each of
+  // the lane's 32 outputs waited for in turn, with nothing else resident on the CU to hide them.
+  constexpr int BN = 32 * TN * WN;
+  __shared__ double s_cmul[I8_BM];   // chain: 2^-vexp (the chain's v grid is 2^-(8S + vexp)), NaN for a flagged chain
+  __shared__ double s_pscale[BN];    // pair: scale, with the sign bit set on the diagonal pairs (scale > 0)
+  __shared__ int s_coff[I8_BM];      // chain: 1 when the chain is written
+  __shared__ int s_poff[BN];         // pair: a DP + b, -1 for padding
+  for (int i = threadIdx.x; i < I8_BM + BN; i += 128 * WN) {
+    if (i < I8_BM) {
+      const int c = cb * I8_BM + i;
+      const bool ok = c < n_chains && phase[min(c, n_chains - 1)] == 1;
+      s_coff[i] = ok ? 1 : 0;
+      s_cmul[i] = ok ? (vbad[c] ? __builtin_nan("") : ldexp(1.0, -vexp[c])) : 0.0;
+    } else {
+      const int j = i - I8_BM, p = pb * BN + j;
+      const bool ok = p < pr.NP;
+      const int a = ok ? pr.pa[p] : 0, b = ok ? pr.pb[p] : 0;
+      s_poff[j] = ok ? a * DP + b : -1;
+      s_pscale[j] = ok ? (a == b ? -pr.scale[p] : pr.scale[p]) : 0.0;
+    }
+  }
+  __syncthreads();
   gemm_i8_tile<S, WN, TN, (WN == 4)>(Vs + (size_t)kb * nCp * 32, Zs + (size_t)kb * pr.NPp * 32, nCp, pr.NPp, nks_total, kn, cb, pb,
                                      n_chains - cb * I8_BM, pr.NP - pb * 32 * TN * WN, [&](int c, int p, double val) {
-    if (c >= n_chains || p >= pr.NP) return;
-    if (phase[c] != 1) return;
-    const int a = pr.pa[p], b = pr.pb[p];  // b <= a: pairs run along the rows of the lower triangle
-    double* gp = Gout + (size_t)c * DP * DP + a * DP + b;  // lower triangle only (contiguous in p): all the factor kernels read
-    double g = ldexp(val * pr.scale[p], -vexp[c]);  // (the chain's v grid is 2^-(8S + vexp))
+    const int ci = c - cb * I8_BM, pj = p - pb * BN;
+    const int off = s_poff[pj];
+    const double ps = s_pscale[pj];
+    const bool ok = s_coff[ci] != 0 && off >= 0;
+    // lower triangle only (pairs run along its rows, contiguous in p): all the factor kernels read
+    double* gp = Gout + (size_t)min(c, n_chains - 1) * DP * DP + max(off, 0);
+    double g = (val * fabs(ps)) * s_cmul[ci];
     if (accumulate) g += *gp;
-    else if (a == b && first) g += inv_alpha;
-    if (vbad[c]) g = __builtin_nan("");
-    *gp = g;
+    else if (ps < 0.0 && first) g += inv_alpha;
+    if (ok) *gp = g;
   });
+}
+
+// The pairs beyond the last FULL block of 32 WN pairs (D = 64: 2080 = 16 x 128 + 32) as tiles of their own.  In the main launch
+// they made a 17th pair block per chain block whose workgroups, three wave columns idle, still took 0.4 of a full tile's time, after
+// the 1024 full tiles had filled the 256 CUs exactly four times over: 2.91 ms against 2.71 ms for 2048 pairs (tools/i8_gemm_probe 70).
+// Here: 128 chains x 32 pairs per two-wave workgroup, the k range in gridDim.y pieces so that the launch fills the chip (the pass is
+// bound by reading V once, 0.10 ms at config 3), int32 accumulators to Tq[piece][g][chain][32 ntail]; k_assemble_i8_tailsum adds
+// the pieces AS INTEGERS and converts once, with the main epilogue's own expression: the G entries are bit-identical to the ones
+// the 17th pair block produced.
+template <int S>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_assemble_i8_tail(
+    const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int NP, int nks_total, int ks0, int nk, int n_chains, int pb32_0,
+    int ntail, int* __restrict__ Tq) {
+  const int nCB = nCp / I8_BM;
+  const int cb = blockIdx.x % nCB, tb = blockIdx.x / nCB;
+  const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kb = ks0 + (int)blockIdx.y * per, kn = min(per, ks0 + nk - kb);
+  int* __restrict__ T = Tq + (size_t)blockIdx.y * S * nCp * 32 * ntail;
+  const int pb32 = pb32_0 + tb;
+  if (kn <= 0) {  // (a piece past the end of the range: its slots must still read as zero)
+    for (int i = threadIdx.x; i < S * I8_BM * 32; i += 128) {
+      const int g = i / (I8_BM * 32), r = i % (I8_BM * 32);
+      T[((size_t)g * nCp + cb * I8_BM + (r >> 5)) * 32 * ntail + tb * 32 + (r & 31)] = 0;
+    }
+    return;
+  }
+  gemm_i8_tile<S, 1, 1, 0, true>(Vs + (size_t)kb * nCp * 32, Zs + (size_t)kb * NPp * 32, nCp, NPp, nks_total, kn, cb, pb32, n_chains - cb * I8_BM,
+                                 NP - pb32 * 32, [&](int c, int p, int g, int a) {
+    T[((size_t)g * nCp + c) * 32 * ntail + (p - pb32_0 * 32)] = a;  // (c < nCp, p inside the tail: padding rows / pairs hold zeros)
+  });
+}
+template <int S>
+__global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restrict__ Tq, int pieces, int nCp, int ntail, int pb32_0, int accumulate,
+                                                             I8Pairs pr, int n_chains, const int* __restrict__ phase, const int* __restrict__ vbad,
+                                                             int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp) {
+  const int W = 32 * ntail;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(i / W), j = (int)(i % W);
+  const int p = pb32_0 * 32 + j;
+  if (c >= n_chains || p >= pr.NP || phase[c] != 1) return;
+  int acc[S];
+#pragma unroll
+  for (int g = 0; g < S; ++g) acc[g] = 0;
+  for (int y = 0; y < pieces; ++y)
+#pragma unroll
+    for (int g = 0; g < S; ++g) acc[g] += Tq[(((size_t)y * S + g) * nCp + c) * W + j];
+  const double val = i8_combine<S>([&](int g) { return acc[g]; });
+  const int a = pr.pa[p], b = pr.pb[p];
+  double* gp = Gq + (size_t)c * DP * DP + a * DP + b;
+  double gv = (val * pr.scale[p]) * (vbad[c] ? __builtin_nan("") : ldexp(1.0, -vexp[c]));
+  if (accumulate) gv += *gp;
+  else if (a == b) gv += inv_alpha;
+  *gp = gv;
 }
 
 // dst[i] = sum over planes of src[plane][i], in plane order (deterministic)
@@ -629,14 +723,30 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
   const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;  // k-split planes as in k_assemble_i8
   const int kb = kp0 + (int)blockIdx.y * per, kn = min(per, kp0 + nk - kb);
   double* __restrict__ Rout = R + (size_t)blockIdx.y * plane_stride;
+  // per-chain and per-row factors of the tile to LDS up front (see k_assemble_i8)
+  constexpr int BN = 32 * TN * WN;
+  __shared__ double s_q[I8_BM], s_z[BN];
+  __shared__ int s_ok[I8_BM];
+  for (int i = threadIdx.x; i < I8_BM + BN; i += 128 * WN) {
+    if (i < I8_BM) {
+      const int c = cb * I8_BM + i;
+      const bool ok = c < n_chains && phase[min(c, n_chains - 1)] == 1;
+      s_ok[i] = ok ? 1 : 0;
+      s_q[i] = ok ? qscale[c] : 0.0;
+    } else {
+      const int n = rb * BN + (i - I8_BM);
+      s_z[i - I8_BM] = n < NRp ? zscale[n] : 0.0;
+    }
+  }
+  __syncthreads();
   gemm_i8_tile<S, WN, TN, (WN == 4)>(Qs + (size_t)kb * nCp * 32, Zt + (size_t)kb * NRp * 32, nCp, NRp, nkp_total, kn, cb, rb,
                                      n_chains - cb * I8_BM, Mp - rb * 32 * TN * WN, [&](int c, int n, double val) {
-    if (c >= n_chains || n >= Mp) return;
-    if (phase[c] != 1) return;
-    const size_t o = (size_t)c * Mp + n;
-    double r = val * qscale[c] * zscale[n];
+    const int ci = c - cb * I8_BM;
+    const bool ok = s_ok[ci] != 0 && n < Mp;
+    const size_t o = (size_t)min(c, n_chains - 1) * Mp + min(n, Mp - 1);  // (always a valid address: the loads below are unconditional)
+    double r = val * s_q[ci] * s_z[n - rb * BN];
     if (mulc) r *= crow[o];
     if (accumulate) r += Rout[o];
-    Rout[o] = r;
+    if (ok) Rout[o] = r;
   });
 }

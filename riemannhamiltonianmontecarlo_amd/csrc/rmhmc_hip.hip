@@ -48,6 +48,8 @@ struct Group {
   int8_t* Qs = nullptr;  // slices of the doubled G^-1 entries, [S][nkp][nCp][32]
   double* qscale = nullptr;
   double *Gpart = nullptr, *Rpart = nullptr;  // k-split planes of small batches ([ksplit][n][DP*DP], [ksplit][n][Mp])
+  int* Tq = nullptr;      // int32 accumulators of the ragged last pair block, [pieces][S][nCp][32 ntail] (k_assemble_i8_tail)
+  int tail_pieces = 1;
   int ksplit_a = 1, ksplit_l = 1;
   int fsplit = 1;  // fp64 assembly of small batches: row ranges per chain (planes in Gpart)
   int* vbad = nullptr;
@@ -87,6 +89,7 @@ struct rmhmc_ctx {
   // int8 metric path (metric_i8.hip.h)
   bool i8 = false;
   int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
+  int i8_tail = -1;          // ragged last pair block as tiles of its own: -1 when it pays (launch_assemble_i8_t), 0 never, 1 always
   int8_t* d_Zs = nullptr;
   int* d_ze = nullptr;
   int8_t* d_Zt = nullptr;   // leverage pass: x_a x_b sliced per data row, [S][nkp][NRp][32]
@@ -241,15 +244,30 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   if (g.ksplit_a > 1) {  // small batch: too few tiles to fill the chip, so the k range is cut into planes that are summed afterwards
     const size_t plane = (size_t)g.n * ctx->DP * ctx->DP;
     hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_a), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks,
-                       0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane, g.vexp);
+                       0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane, g.vexp, nPB);
     hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.Gq, g.Gpart, g.ksplit_a, plane, plane);
     return;
   }
+  // Ragged last pair block (D = 64: 2080 pairs = 16 blocks of 128 + 32): once the full blocks alone fill the chip, the rest goes to
+  // k_assemble_i8_tail (bit-identical results, see there).  RMHMC_I8_TAIL=0 / 1: never / whenever there is a ragged block.
+  const int nPBfull = ctx->pairs.NP / (32 * TN * WN);
+  const bool tail = WN == 4 && g.Tq && nPBfull < nPB && (ctx->i8_tail == 1 || (ctx->i8_tail < 0 && (long long)nCB * nPBfull >= 256));
+  const int npb = tail ? nPBfull : nPB;
+  const unsigned nblk_main = (unsigned)(nCB < 8 ? nCB * npb : (nCB + 7) / 8 * 8 * npb);
+  const int pb32_0 = nPBfull * TN * WN, ntail = (ctx->pairs.NP - pb32_0 * 32 + 31) / 32;
   // the k range in pieces whose int32 sums cannot overflow whatever the data (one piece up to M = 21845 at 6 slices)
   for (int ks0 = 0; ks0 < ctx->i8_nks; ks0 += ctx->i8_chunk) {
     const int nk = std::min(ctx->i8_chunk, ctx->i8_nks - ks0);
-    hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp,
-                       ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0, g.vexp);
+    if (nblk_main)
+      hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk_main), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp,
+                         ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0, g.vexp, npb);
+    if (tail) {
+      const int pieces = std::max(1, std::min({g.tail_pieces, nk / 8, (int)(256 / std::max(1, nCB * ntail))}));
+      hipLaunchKernelGGL((k_assemble_i8_tail<S>), dim3((unsigned)(nCB * ntail), (unsigned)pieces), dim3(128), (i8_lds_bytes<S, 1, 1>()), st, g.Vs, ctx->d_Zs,
+                         g.nCp, ctx->pairs.NPp, ctx->pairs.NP, ctx->i8_nks, ks0, nk, g.n, pb32_0, ntail, g.Tq);
+      hipLaunchKernelGGL((k_assemble_i8_tailsum<S>), dim3((unsigned)(((size_t)g.n * 32 * ntail + 255) / 256)), dim3(256), 0, st, g.Tq, pieces, g.nCp, ntail,
+                         pb32_0, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp);
+    }
   }
 }
 // leverage pass of the int8 path: part 0 cuts G^-1 into slices, part 1 is the GEMM (R = c .* h into rv0, v is dead by then)
@@ -751,6 +769,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   }
   ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
   if (const char* e = getenv("RMHMC_CCACHE")) ctx->ccache = atoi(e) != 0;
+  if (const char* e = getenv("RMHMC_I8_TAIL")) ctx->i8_tail = atoi(e) ? 1 : 0;
   int rc = RMHMC_OK;
   auto body = [&]() -> int {
     HIPCK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -877,14 +896,22 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         g.ksplit_a = pieces((long long)(g.nCp / I8_BM) * (NPp / ctx->i8_bn), ctx->i8_nks);
         g.ksplit_l = pieces((long long)(g.nCp / I8_BM) * (ctx->i8_NRp / ctx->i8_bn), ctx->i8_nkp);
         if (g.ksplit_a > 1) RC(dalloc(ctx, &g.Gpart, (size_t)g.ksplit_a * g.n * ctx->DP * ctx->DP));
+        if (g.ksplit_a == 1 && ctx->i8_bn == 128 && NP % 128 != 0 && ctx->i8_tail != 0) {
+          const int ntail = (NP % 128 + 31) / 32;
+          g.tail_pieces = (int)std::max<long long>(1, std::min<long long>(8, 256 / ((long long)(g.nCp / I8_BM) * ntail)));
+          RC(dalloc(ctx, &g.Tq, (size_t)g.tail_pieces * S * g.nCp * 32 * ntail));
+        }
         if (g.ksplit_l > 1) RC(dalloc(ctx, &g.Rpart, (size_t)g.ksplit_l * g.n * ctx->Mp));
       }
       I8_SWITCH(ctx, {
         constexpr int lds = i8_lds_bytes<S_, WN_, TN_>();
+        // (the instantiation's own, fixed size: these kernels also hold a few KB of static LDS, and static + dynamic must stay within 160 KB)
         auto kfn = k_assemble_i8<S_, WN_, TN_>;
-        HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+        HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         auto kfn2 = k_leverage_i8<S_, WN_, TN_>;
-        HIPCK(hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
+        HIPCK(hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        auto kfn3 = k_assemble_i8_tail<S_>;
+        HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
       });
     }
     for (Group& g : ctx->groups) {  // planes of the fp64 small-batch assembly (shared with the int8 k-split planes, whichever is larger)

@@ -166,3 +166,22 @@ def test_full_size_config3(hip, oracle):
     o = _run(oracle, M, D, R, XX, t, lambda c: c.transition(w8, z8, ul8, gd8, ua8, L=2, eps=0.5, K=4), 0)
     assert np.array_equal(r["nsteps"][:R], o["nsteps"]) and np.array_equal(r["accepted"][:R], o["accepted"])
     assert rel_err(r["w_prop"][:R], o["w_prop"]) < 1e-8 and rel_err(r["hld_prop"][:R], o["hld_prop"]) < 1e-8
+
+
+@pytest.mark.parametrize("M,D,n,S", [(400, 40, 300, 6), (1000, 40, 2432, 6), (400, 40, 300, 5), (900, 64, 2100, 6)])
+def test_ragged_pair_block_as_tiles_of_its_own_is_bit_identical(hip, monkeypatch, M, D, n, S):
+    """The pairs beyond the last full block of 128 (D = 64: 2080 = 16 x 128 + 32) run as two-wave tiles of their own, k range in
+    pieces summed as integers (k_assemble_i8_tail / _tailsum): same bits as the one-launch form, for one and for several pieces
+    (2432 chains x 7 pair blocks and 2100 x 17: no k split of the main launch, 4 / 3 tail pieces)."""
+    XX, t = synthetic_logreg(M, D, 3)
+    rs = np.random.RandomState(n + S)
+    w = 0.4 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
+    dirs = np.where(rs.rand(n) < 0.5, -1, 1).astype(np.int32)
+    out = {}
+    for tail in ("0", "1"):
+        monkeypatch.setenv("RMHMC_I8_TAIL", tail)
+        with hip.context(M, D, n, flags=_capi.int8_metric_flags(S)) as ctx:
+            ctx.set_data(XX, t, 100.0)
+            out[tail] = ctx.metric(w) + ctx.leapfrog(w, p, 0.5, dirs, 2, 4)
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)

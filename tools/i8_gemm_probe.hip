@@ -91,6 +91,19 @@ int main(int argc, char** argv) {
       run_case<6, 4, 1, 1>(300, 300, 1000, true, 0);
       return 0;
     }
+    if (S == 70) {  // where the time of a tile goes: whole rounds vs a ragged last one, fixed cost per tile (k sweep at the leverage shape),
+                    // and the 128 x 32 two-wave tile that would take the 32 left-over pairs of the assembly (with and without a k split)
+      run_case<6, 4, 1, 1>(8192, 2080, 10000, false, 8);
+      run_case<6, 4, 1, 1>(8192, 2048, 10000, false, 8);
+      run_case<6, 4, 1, 1>(8192, 10000, 2080, false, 8);
+      run_case<6, 4, 1, 1>(8192, 10000, 4160, false, 4);
+      run_case<6, 4, 1, 1>(8192, 10000, 1040, false, 8);
+      run_case<6, 1, 1, 0>(300, 32, 1000, true, 0);
+      run_case<6, 1, 1, 0>(8192, 32, 10000, false, 8);
+      run_case<6, 1, 1, 0>(32768, 32, 2500, false, 8);
+      run_case<6, 1, 1, 0>(65536, 32, 1250, false, 8);
+      return 0;
+    }
     if (S == 22) {  // 4 waves, 64x64 wave tile, one wave per SIMD (512 registers): a third fewer LDS fragment reads per MFMA
       run_case<6, 2, 2, 1>(300, 300, 1000, true, 0);
       run_case<6, 2, 2, 1>(8192, 2080, 10000, false, 5);
