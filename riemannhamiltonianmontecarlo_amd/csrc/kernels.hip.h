@@ -115,13 +115,17 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 //          X'(t - e^f/(1+e^f)) (rmhmc.py:100,140; a fourth small GEMM whose B operand is the accumulator
 //          layout of F, as in k_mompass) and of the log joint sum_n f t - log(1+e^f)   (rmhmc.py:167-168)
 // The naive exp/log forms are kept on purpose: they overflow exactly where the reference does.
-// Accumulator register r of lane l holds data row (l>>4)+4r of the tile and chain l&15.
+// Row assignment inside a 16-row tile ("row-permuted"): MFMA row i of the F product is data row rm_perm16(i) = 4 (i & 3) + (i >> 2),
+// so that accumulator register r of lane l holds data row 4 (l>>4) + r and chain l&15: a lane's four values are four CONSECUTIVE
+// data rows.  The permuted A operand is still one 128-byte line per 16 lanes; the row vectors in natural layout (v, c, R) go out and
+// come in as one 32-byte access per lane, and the byte slices of v need no cross-lane transpose.  k_mompass and k_trvec use the same
+// assignment (the c tiles of k_rowpass<RP_F> are read by k_mompass<.., 2>).
 // ---------------------------------------------------------------------------------------------
 enum { RP_V = 0, RP_F = 1, RP_G = 2 };  // RP_G: as RP_F without the v / c row vectors (plain HMC)
+__device__ __forceinline__ int rm_perm16(int i) { return 4 * (i & 3) + (i >> 2); }
 
 // int8 metric path (metric_i8.hip.h): the row pass emits v already cut into signed-byte slices, Vs[S][nks][nCp][32], instead of the
-// fp64 row vector.  A lane holds rows rr, rr+4, rr+8, rr+12 of a 16-row block for its chain; a 4x4 byte transpose over the four
-// lanes of the chain (two butterfly shuffles) gives every lane four CONSECUTIVE rows, i.e. one dword of the slice plane.
+// fp64 row vector.  A lane holds four consecutive rows of a 16-row block for its chain (see above), i.e. one dword of every slice plane.
 struct VSlice {
   int8_t* Vs;
   int* vbad;   // raised when a v is not in [0, 1/4] (non-finite: diverged chain); cleared by the host before the pass
@@ -133,20 +137,16 @@ struct VSlice {
   int* vexp;
   const double *cmin, *cmax;
 };
-__device__ __forceinline__ unsigned transpose4x4_bytes(unsigned p, int rr) {
-  const unsigned a = (unsigned)__shfl_xor((int)p, 16, 64);
-  const unsigned t1 = (rr & 1) ? (((a >> 8) & 0x00FF00FFu) | (p & 0xFF00FF00u)) : ((p & 0x00FF00FFu) | ((a & 0x00FF00FFu) << 8));
-  const unsigned b = (unsigned)__shfl_xor((int)t1, 32, 64);
-  return (rr & 2) ? ((b >> 16) | (t1 & 0xFFFF0000u)) : ((t1 & 0x0000FFFFu) | (b << 16));
-}
-
-template <int NB, int MODE, bool I8 = false>
+// I8S: 0 = fp64 row vectors, else the number of byte slices (compile time: the slicing code is straight-line)
+// (the slicing RP_F variant takes 190 VGPRs = 2 waves per SIMD; asked for 3 / 4 waves it spills: rowpass 2.51 -> 2.99 / 3.57 ms per step)
+template <int NB, int MODE, int I8S = 0>
 __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
                                                  double* __restrict__ out2, double* __restrict__ gpart,
                                                  double* __restrict__ ljl_part, VSlice vs = VSlice{}, d4* __restrict__ ctile = nullptr) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
+  constexpr bool I8 = I8S > 0;
   const int lane = threadIdx.x & 63;
   const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
   if (c0 >= n_chains) return;
@@ -175,25 +175,26 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
   }
   double vscale = 1.0, vmagic = 4503599627370496.0;  // 2^(8S + vexp) and 2^52 + B (fast slicing, S <= 6)
   if (I8 && MODE != RP_G) {
-    vscale = ldexp(1.0, 8 * vs.S + vsh);
+    vscale = ldexp(1.0, 8 * I8S + vsh);
     double bsum = 0.0;
-    for (int j = 0; j < vs.S && j < 6; ++j) bsum += ldexp(128.0, 8 * j);
+#pragma unroll
+    for (int j = 0; j < I8S && j < 6; ++j) bsum += ldexp(128.0, 8 * j);
     vmagic += bsum;
   }
   const int nb16 = dd.Mp / 16;
   const int per = (nb16 + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(nb16, b0 + per);
-  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + ci;  // A: X[n0+ci][4kk+rr]
-  const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;   // A of the gradient product
+  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + rm_perm16(ci);  // A: X[n0+perm(ci)][4kk+rr]
+  const double* __restrict__ xr_p = dd.Xr + (size_t)(4 * rr) * DP + NB * ci;      // A of the gradient product: X[n0+4rr+r][NB ci+I]
   double lj = 0.0;
   int bad = 0;
   d4 Gr[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Gr[I] = (d4){0.0, 0.0, 0.0, 0.0};
   // Software pipeline as in k_mompass: the A operand of the next tile's F product is requested before the matrix instructions of the
-  // current tile (two register sets), the A operand of the gradient product at the start of its own tile.  Not for the variant that
-  // also cuts v into byte slices (I8): there the extra live registers cost more than the exposed latency (rowpass 2.73 -> 2.90 ms per
-  // step with the pipeline, against 2.33 -> 2.06 for the fp64 variants), so it keeps the compiler's own schedule at 5 waves per SIMD.
+  // current tile (two register sets), the A operand of the gradient product at the start of its own tile.  Not for the variants that
+  // also cut v into byte slices (I8): measured again with the straight-line slicing code, rowpass 2.49 ms per step without, 2.71 with
+  // the pipeline in RP_F, 2.51 with it in RP_V (fp64 variants: 2.33 -> 2.06).
   constexpr bool PIPE = !I8;
   double A0[KK], A1[KK];
   auto load_a = [&](double (&A)[KK], int b) {
@@ -207,48 +208,46 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + 4 * r) * DP + I];
+        for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + r) * DP + I];
     }
     if (PIPE) __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above the products below)
     d4 F = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
-    double vv[4];
-    d4 cc = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 vv, cc = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nl = n0 + 4 * rr;  // the lane's four data rows nl .. nl+3
+    d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};
+    if (MODE != RP_V) t4 = *(const d4*)(dd.t + nl);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + rr + 4 * r;
+      const int n = nl + r;
       const double f = F[r];
       const double em = exp(-f);
       const double p = 1.0 / (1.0 + em);
       const double v = p * (1.0 - p);
       vv[r] = v;
       cc[r] = v * (1.0 - 2.0 * p);
-      const size_t o = (size_t)cj * dd.Mp + n;
-      if (MODE == RP_V) {
-        if (live && !I8) out0[o] = v;
-      } else {
+      if (MODE != RP_V) {
         const double ef = exp(f);
-        const double tn = dd.t[n];
-        if (MODE == RP_F && live) {
-          if (!I8) out0[o] = v;
-          out2[o] = v * (1.0 - 2.0 * p);
-        }
+        const double tn = t4[r];
         if (n < dd.M) lj += f * tn - log(1.0 + ef);
         const double rn = tn - ef / (1.0 + ef);  // padded rows: x = 0, no contribution
 #pragma unroll
         for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rn, Gr[I], 0, 0, 0);
       }
     }
-    // c in the accumulator layout, for k_mompass<NB, 2> at the same position (same chain group / row block / lane mapping)
-    if (MODE == RP_F && ctile && live) ctile[((size_t)(c0 >> 4) * nb16 + b) * 64 + lane] = cc;
-    if (I8 && MODE != RP_G) {
-      // byte k of Q[j] = digit j (least significant first) of rint(v 2^(8S + vexp)) for the lane's row rr + 4k; all lanes take part in
-      // the shuffles, only live chains and stages inside the slice planes are stored
-      unsigned Q[7];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) Q[j] = 0u;
-      if (vs.S <= 6) {
+    if (live) {  // row vectors in natural layout: 32 contiguous bytes per lane
+      const size_t o = (size_t)cj * dd.Mp + nl;
+      if (MODE != RP_G && !I8) *(d4*)(out0 + o) = vv;
+      if (MODE == RP_F) *(d4*)(out2 + o) = cc;
+      // c in the accumulator layout, for k_mompass<NB, 2> at the same position (same chain group / row block / lane mapping)
+      if (MODE == RP_F && ctile) ctile[((size_t)(c0 >> 4) * nb16 + b) * 64 + lane] = cc;
+    }
+    if constexpr (I8 && MODE != RP_G) {
+      // byte k of Q[j] = digit j (least significant first) of rint(v 2^(8S + vexp)) for the lane's row nl + k: one dword of slice
+      // plane S-1-j; only live chains and stages inside the slice planes are stored
+      unsigned Q[I8S > 0 ? I8S : 1];
+      if constexpr (I8S <= 6) {
         // Fast path (at most 48 bits).  N = rint(x 2^k) = sum_j d_j 256^j with balanced digits d_j in [-128, 127]  <=>  N + B, B = sum_j<S
         // 128 256^j, has the UNSIGNED bytes d_j + 128.  One fma puts N + B into the mantissa of a double in [2^52, 2^53) (round to
         // nearest even at ulp 1: the same rounding as rint), so the digits are the mantissa bytes xor 0x80; a 4 x 6 byte transpose
@@ -264,46 +263,49 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
         }
         const unsigned a = __builtin_amdgcn_perm(L[1], L[0], 0x05010400u), b2 = __builtin_amdgcn_perm(L[1], L[0], 0x07030602u);
         const unsigned c = __builtin_amdgcn_perm(L[3], L[2], 0x05010400u), d2 = __builtin_amdgcn_perm(L[3], L[2], 0x07030602u);
-        Q[0] = __builtin_amdgcn_perm(c, a, 0x05040100u) ^ 0x80808080u;
-        Q[1] = __builtin_amdgcn_perm(c, a, 0x07060302u) ^ 0x80808080u;
-        Q[2] = __builtin_amdgcn_perm(d2, b2, 0x05040100u) ^ 0x80808080u;
-        Q[3] = __builtin_amdgcn_perm(d2, b2, 0x07060302u) ^ 0x80808080u;
+        unsigned Qf[6];
+        Qf[0] = __builtin_amdgcn_perm(c, a, 0x05040100u) ^ 0x80808080u;
+        Qf[1] = __builtin_amdgcn_perm(c, a, 0x07060302u) ^ 0x80808080u;
+        Qf[2] = __builtin_amdgcn_perm(d2, b2, 0x05040100u) ^ 0x80808080u;
+        Qf[3] = __builtin_amdgcn_perm(d2, b2, 0x07060302u) ^ 0x80808080u;
         const unsigned ah = __builtin_amdgcn_perm(H[1], H[0], 0x05010400u), ch = __builtin_amdgcn_perm(H[3], H[2], 0x05010400u);
-        Q[4] = __builtin_amdgcn_perm(ch, ah, 0x05040100u) ^ 0x80808080u;
-        Q[5] = __builtin_amdgcn_perm(ch, ah, 0x07060302u) ^ 0x80808080u;
+        Qf[4] = __builtin_amdgcn_perm(ch, ah, 0x05040100u) ^ 0x80808080u;
+        Qf[5] = __builtin_amdgcn_perm(ch, ah, 0x07060302u) ^ 0x80808080u;
+#pragma unroll
+        for (int j = 0; j < I8S; ++j) Q[j] = Qf[j];
       } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double x = vv[r];
-        if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
-        // N = rint(x 2^(8S)) < 2^(8S-2) as two 32-bit words split at bit 24 (all in exact fp64 / int32 arithmetic: no 64-bit
-        // integer emulation): three balanced digits from the low word, the carry and up to four more from the high word
-        const double y = rint(ldexp(x, 8 * vs.S + vsh));
-        const double yh = floor(y * 5.9604644775390625e-08);  // 2^-24
-        int lo = (int)(y - yh * 16777216.0), hi = (int)yh;
+        for (int j = 0; j < I8S; ++j) Q[j] = 0u;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int bt = (int)(signed char)(lo & 0xFF);
-          Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
-          lo = (lo - bt) >> 8;
-        }
-        hi += lo;  // carry out of the low word
+        for (int r = 0; r < 4; ++r) {
+          double x = vv[r];
+          if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
+          // N = rint(x 2^(8S)) < 2^(8S-2) as two 32-bit words split at bit 24 (all in exact fp64 / int32 arithmetic: no 64-bit
+          // integer emulation): three balanced digits from the low word, the carry and up to four more from the high word
+          const double y = rint(ldexp(x, 8 * I8S + vsh));
+          const double yh = floor(y * 5.9604644775390625e-08);  // 2^-24
+          int lo = (int)(y - yh * 16777216.0), hi = (int)yh;
 #pragma unroll
-        for (int j = 3; j < 7; ++j) {
-          const int bt = (int)(signed char)(hi & 0xFF);
-          Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
-          hi = (hi - bt) >> 8;
+          for (int j = 0; j < 3; ++j) {
+            const int bt = (int)(signed char)(lo & 0xFF);
+            Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
+            lo = (lo - bt) >> 8;
+          }
+          hi += lo;  // carry out of the low word
+#pragma unroll
+          for (int j = 3; j < I8S; ++j) {
+            const int bt = (int)(signed char)(hi & 0xFF);
+            Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
+            hi = (hi - bt) >> 8;
+          }
         }
-      }
       }
       const int ks = n0 >> 5;
-      const bool st = live && ks < vs.nks;
+      if (live && ks < vs.nks) {
+        int8_t* vp = vs.Vs + ((size_t)ks * vs.nCp + cj) * 32 + (n0 & 31) + 4 * rr;
+        const size_t plane = (size_t)vs.nks * vs.nCp * 32;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        if (j < vs.S) {  // wave-uniform
-          const unsigned tq = transpose4x4_bytes(Q[j], rr);
-          if (st) *(unsigned*)(vs.Vs + (((size_t)(vs.S - 1 - j) * vs.nks + ks) * vs.nCp + cj) * 32 + (n0 & 31) + 4 * rr) = tq;
-        }
+        for (int j = 0; j < I8S; ++j) *(unsigned*)(vp + (size_t)(I8S - 1 - j) * plane) = Q[j];
       }
     }
   };
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, 
 // K3b  fused quadratic-term pass on the matrix cores, 16 chains per wavefront:
 //        q_c[d] = sum_n c_n(w_c) (x_n.u_c)^2 x_nd  = u' dG/dw_d u      (rmhmc.py:104-107,158-161)
 // as three small GEMMs per 16 data rows:  F = X W, S = X U  (16 rows x 16 chains, K = D) and
-// Q += X' R with R = c(F) S^2.  The accumulator layout of F/S (register r <-> data row (lane>>4)+4r,
+// Q += X' R with R = c(F) S^2.  The accumulator layout of F/S (register r <-> data row 4(lane>>4)+r,
 // column lane&15 = chain) is exactly the B-operand layout of the third product for the 4-row chunk r,
 // so R feeds the matrix core without any lane movement.  X is read once per 16 chains.
 // Rows are split over blockIdx.y; partial sums go to qpart[split][chain][d] (summed, in fixed order,
@@ -534,8 +536,8 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
   d4 Q[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Q[I] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + ci;     // A of F,S: X[n0+ci][4kk+rr]
-  const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;   // A of Q  : X[n0+4r+rr][NB*ci+I]
+  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + rm_perm16(ci);   // A of F,S: X[n0+perm(ci)][4kk+rr] (row-permuted tile, see k_rowpass)
+  const double* __restrict__ xr_p = dd.Xr + (size_t)(4 * rr) * DP + NB * ci;       // A of Q  : X[n0+4rr+r][NB*ci+I]
   // Software pipeline over the 16-row tiles: the A operand of F / S (and c) of the NEXT tile is requested before the matrix instructions
   // of the current one, and the A operand of Q of the current tile at its start, behind the F / S products.  Left to itself the
   // compiler keeps two A registers in flight and puts an s_waitcnt vmcnt(1) in front of every MFMA: a wave then pays the L2 latency
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(b * 16 + 4 * r) * DP + I];
+      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(b * 16 + r) * DP + I];
     __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above the products below)
     d4 F = (d4){0.0, 0.0, 0.0, 0.0}, S = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1441,20 +1443,19 @@ __global__ __launch_bounds__(256) void k_trvec(DevData dd, int n_chains, int nsp
   const int nb16 = dd.Mp / 16;
   const int per = (nb16 + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(nb16, b0 + per);
-  const double* __restrict__ xr_p = dd.Xr + (size_t)rr * DP + NB * ci;
-  const double* __restrict__ rp = R + (size_t)cj * dd.Mp + rr;
+  const double* __restrict__ xr_p = dd.Xr + (size_t)(4 * rr) * DP + NB * ci;  // (row-permuted tile: the lane's rows are n0+4rr .. +3)
+  const double* __restrict__ rp = R + (size_t)cj * dd.Mp + 4 * rr;
   d4 T[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) T[I] = (d4){0.0, 0.0, 0.0, 0.0};
   for (int b = b0; b < b1; ++b) {
     const int n0 = b * 16;
-    double rv[4], xb[4][NB];
+    double xb[4][NB];
+    const d4 rv = *(const d4*)(rp + n0);  // 32 contiguous bytes per lane
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      rv[r] = rp[n0 + 4 * r];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + 4 * r) * DP + I];
-    }
+      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + r) * DP + I];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll

@@ -208,6 +208,14 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
     default: { constexpr int NB_ = 4; __VA_ARGS__; } break;               \
   }
 
+#define I8_SWITCH(ctx, ...)                                                        \
+  switch ((ctx)->i8S) {                                                            \
+    case 4: { constexpr int S_ = 4, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
+    case 5: { constexpr int S_ = 5, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
+    case 6: { constexpr int S_ = 6, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
+    default: { constexpr int S_ = 7, WN_ = 2, TN_ = 1; __VA_ARGS__; } break;       \
+  }
+
 template <int MODE>
 void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out2 = nullptr) {
   launch(ctx, g, HEAVY, "rowpass", [&](hipStream_t st) {
@@ -221,8 +229,8 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
     if (ctx->i8 && MODE != RP_G) {  // int8 metric path: v goes out as byte slices (no fp64 row vector, no k_vsplit)
       (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
       const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
-      NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                        out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile));
+      I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
+                                                      out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
       return;
     }
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
@@ -295,14 +303,6 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
                        g.ch.rv2, g.ch.rv0, (size_t)0);
   }
 }
-#define I8_SWITCH(ctx, ...)                                                        \
-  switch ((ctx)->i8S) {                                                            \
-    case 4: { constexpr int S_ = 4, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
-    case 5: { constexpr int S_ = 5, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
-    case 6: { constexpr int S_ = 6, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
-    default: { constexpr int S_ = 7, WN_ = 2, TN_ = 1; __VA_ARGS__; } break;       \
-  }
-
 void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
   if (ctx->i8) {
     if (ctx->big)  // (the generic row pass already wrote the slices)
