@@ -196,7 +196,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    KT_NAMES = ("assemble", "assemble_i8", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small",
+    KT_NAMES = ("assemble", "assemble_i8", "assemble_i8_inner", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small",
                 "fused", "medium", "total")
     # un-timed repetition of the same K steps with HIP events around every launch (on the library's own stream)
     ctx.kernel_time("enable"); ctx.kernel_time("reset")
@@ -296,6 +296,11 @@ def main():
                     "fp64_equivalent_tflops": 2.0 * n * M * NP / i_avg / 1e12,
                     "fp64_equivalent_frac_of_fp64_mfma_peak": 2.0 * n * M * NP / i_avg / FP64_MFMA_PEAK,
                     "vsplit_avg_launch_ms": kt["vsplit"][0] / max(1, kt["vsplit"][1]) * 1e3,
+                    # the assemblies of the position fixed-point iterates before the last: the 5 most significant slices (15 products)
+                    "inner_iterate_assembly": ({"slices": S - 1, "launches": kt["assemble_i8_inner"][1],
+                                                "avg_launch_ms": kt["assemble_i8_inner"][0] / kt["assemble_i8_inner"][1] * 1e3,
+                                                "frac": 2.0 * n * M * NP * ((S - 1) * S // 2) / (kt["assemble_i8_inner"][0] / kt["assemble_i8_inner"][1]) / INT8_MFMA_PEAK}
+                                               if kt["assemble_i8_inner"][1] else None),
                     "survey8d_streaming_model_frac_NOT_A_BOUND": (value / world) * bytes_step / HBM_PEAK,
                     "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
                     "note": "survey8d_streaming_model_frac = steps/s x 80 M D bytes / 8 TB/s, the figure SURVEY 8(d) / north_star ask for; it can "
@@ -338,12 +343,16 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "dtype_detail": ("f64 throughout; the two O(M D^2) contractions (metric assembly, leverages) as exact integer GEMMs: operands cut into %d "
-                             "signed-byte slices, int8 MFMA with int32 accumulation, combined in f64 (G to ~2e-14 of the f64 oracle at 6 slices)"
-                             % args.i8_slices) if args.i8_slices else "f64 throughout (fp64 matrix cores)",
+                             "signed-byte slices, int8 MFMA with int32 accumulation, combined in f64 (G to ~2e-14 of the f64 oracle at 6 slices)%s"
+                             % (args.i8_slices, "; the metric of the position fixed-point iterates before the last (it only steers the next iterate) "
+                                "from the 5 most significant slices (effect on theta after a step < 1e-11)" if args.i8_slices == 6 else ""))
+                            if args.i8_slices else "f64 throughout (fp64 matrix cores)",
             "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
                        "D": D, "M": M, "leapfrog_L": L, "step_size": eps, "fixed_point_K": K,
-                       "compat": bool(args.compat), "metric_assembly": ("int8 x %d slices" % args.i8_slices) if args.i8_slices else "fp64",
+                       "compat": bool(args.compat), "metric_assembly": (("int8 x %d slices" % args.i8_slices) + (" (position fixed-point iterates before the last: 5; "
+                                           "RMHMC_FLAG_INT8_INNER_FULL = 6 everywhere, see alternates.int8_x6_inner_full)" if args.i8_slices == 6 else ""))
+                       if args.i8_slices else "fp64",
                        "int8_error_certificate": i8_bound if i8_bound > 0 else None, "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "roofline": roof,
             "kernel_seconds": {k: {"seconds": v[0], "launches": v[1]} for k, v in kt.items()},
@@ -362,8 +371,8 @@ def main():
     if rank == 0:
         big = 8 < D <= 256 and n * float(M) * D * D >= 1e9
 
-        def run_variant(sl, steps, timing):
-            c2 = lib.context(M, D, n, flags=flags | (_capi.int8_metric_flags(sl) if sl else 0), device=dev)
+        def run_variant(sl, steps, timing, extra=0):
+            c2 = lib.context(M, D, n, flags=flags | extra | (_capi.int8_metric_flags(sl) if sl else 0), device=dev)
             c2.set_data(XX, t)
             c2.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
             c2.chains_run(min(args.warmup, 2) or 1)
@@ -401,6 +410,8 @@ def main():
                 if sl == args.i8_slices or (sl == 0 and "roofline_fp64" in out):
                     continue
                 alts[name], _ = run_variant(sl, 3, False)
+            if args.i8_slices == 6:   # all four assemblies of a step from 6 slices
+                alts["int8_x6_inner_full"], _ = run_variant(6, 3, False, _capi.FLAG_INT8_INNER_FULL)
             if "roofline_fp64" in out:
                 alts["fp64_mfma"] = {"value": out["roofline_fp64"]["value"], "ms_per_step": out["roofline_fp64"]["ms_per_step"]}
             out["alternates"] = alts

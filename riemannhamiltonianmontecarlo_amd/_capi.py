@@ -18,6 +18,7 @@ FLAG_FP32_METRIC = 1 << 4
 FLAG_INT8_METRIC = 1 << 5
 FLAG_MMALA_FULL = 1 << 6
 FLAG_INT8_CERTIFY = 1 << 7
+FLAG_INT8_INNER_FULL = 1 << 10   # int8 x 6 slices: position iterates before the last also from all 6 slices (default: 5)
 FLAG_ESS_WRAP = 1 << 9      # ESS with the reference Python's wrapped FFT length (tools.py:23); default = MATLAB (no wrap)
 INT8_CERTIFY_TOL = 1e-9
 

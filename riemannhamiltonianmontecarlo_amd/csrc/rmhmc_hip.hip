@@ -89,6 +89,7 @@ struct rmhmc_ctx {
   // int8 metric path (metric_i8.hip.h)
   bool i8 = false;
   int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
+  int i8_inner_drop = 1;     // inner assemblies from S-1 slices (launch_assemble; RMHMC_FLAG_INT8_INNER_FULL / RMHMC_I8_INNER_DROP=0: off)
   int i8_tail = -1;          // ragged last pair block as tiles of its own: -1 when it pays (launch_assemble_i8_t), 0 never, 1 always
   int8_t* d_Zs = nullptr;
   int* d_ze = nullptr;
@@ -208,8 +209,9 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
     default: { constexpr int NB_ = 4; __VA_ARGS__; } break;               \
   }
 
-#define I8_SWITCH(ctx, ...)                                                        \
-  switch ((ctx)->i8S) {                                                            \
+#define I8_SWITCH(ctx, ...) I8_SWITCH_S((ctx)->i8S, __VA_ARGS__)
+#define I8_SWITCH_S(sval, ...)                                                     \
+  switch (sval) {                                                                  \
     case 4: { constexpr int S_ = 4, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
     case 5: { constexpr int S_ = 5, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
     case 6: { constexpr int S_ = 6, WN_ = 4, TN_ = 1; __VA_ARGS__; } break;        \
@@ -303,11 +305,15 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
                        g.ch.rv2, g.ch.rv0, (size_t)0);
   }
 }
-void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v) {
+// inner: an assembly whose G only steers a fixed-point iterate (the position iterations before the last, rmhmc.py:116-122).  With
+// ctx->i8_inner_drop it is summed from the S-1 most significant slices of the same operands (balanced digits: dropping the last digit
+// IS rounding to the coarser grid), 15 slice products instead of 21.
+void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = false) {
   if (ctx->i8) {
     if (ctx->big)  // (the generic row pass already wrote the slices)
       launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 0))); });
-    launch(ctx, g, HEAVY, "assemble_i8", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 1))); });
+    const int suse = (inner && ctx->i8_inner_drop && ctx->i8S == 6) ? 5 : ctx->i8S;  // (5 -> 4 costs parity: 2e-9 on theta at M = 97)
+    launch(ctx, g, HEAVY, suse == ctx->i8S ? "assemble_i8" : "assemble_i8_inner", [&](hipStream_t st) { I8_SWITCH_S(suse, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 1))); });
     return;
   }
   launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
@@ -509,7 +515,7 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   }
   for (int it = 1; it < K; ++it) {
     ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0); });
-    ph.push_back([=](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
+    ph.push_back([=](Group& g) { launch_assemble(ctx, g, g.ch.rv0, it < K - 1); });
     if (ctx->big)
       ph.push_back([=](Group& g) { BIG(ctx, g, "factor", k_chol_big<0>, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096, eps); });
     else
@@ -770,6 +776,8 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
   if (const char* e = getenv("RMHMC_CCACHE")) ctx->ccache = atoi(e) != 0;
   if (const char* e = getenv("RMHMC_I8_TAIL")) ctx->i8_tail = atoi(e) ? 1 : 0;
+  if (flags & RMHMC_FLAG_INT8_INNER_FULL) ctx->i8_inner_drop = 0;
+  if (const char* e = getenv("RMHMC_I8_INNER_DROP")) ctx->i8_inner_drop = atoi(e) ? 1 : 0;
   int rc = RMHMC_OK;
   auto body = [&]() -> int {
     HIPCK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -913,6 +921,13 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         auto kfn3 = k_assemble_i8_tail<S_>;
         HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
       });
+      if (S == 6)  // the instantiations of the inner assemblies (launch_assemble)
+        I8_SWITCH_S(S - 1, {
+          auto kfn = k_assemble_i8<S_, WN_, TN_>;
+          HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, WN_, TN_>())));
+          auto kfn3 = k_assemble_i8_tail<S_>;
+          HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
+        });
     }
     for (Group& g : ctx->groups) {  // planes of the fp64 small-batch assembly (shared with the int8 k-split planes, whichever is larger)
       const int need = std::max(g.fsplit, g.ksplit_a);

@@ -185,3 +185,28 @@ def test_ragged_pair_block_as_tiles_of_its_own_is_bit_identical(hip, monkeypatch
             out[tail] = ctx.metric(w) + ctx.leapfrog(w, p, 0.5, dirs, 2, 4)
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("M,D,n", [(1000, 64, 130), (203, 33, 7), (3000, 25, 257), (10000, 64, 128)])
+def test_inner_iterates_from_five_slices(hip, oracle, M, D, n):
+    """At 6 slices the metric of the position fixed-point iterates before the last one is summed from the 5 most significant slices
+    (it only steers the next iterate; RMHMC_FLAG_INT8_INNER_FULL turns that off).  G, log det and everything else of an EVALUATION
+    point are untouched (bit-identical), theta / p after leapfrog steps move by < 1e-11, and both stay within 1e-9 of the oracle."""
+    XX, t = synthetic_logreg(M, D, 5)
+    rs = np.random.RandomState(M + n)
+    w = 0.4 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
+    dirs = np.where(rs.rand(n) < 0.5, -1, 1).astype(np.int32)
+
+    def fn(ctx):
+        return ctx.metric(w) + ctx.leapfrog(w, p, 0.5, dirs, 3, 4)
+
+    fast = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(6))
+    full = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(6) | _capi.FLAG_INT8_INNER_FULL)
+    ref = _run(oracle, M, D, n, XX, t, fn, 0)
+    for k in range(3):   # G, half log det, gradient at w
+        assert np.array_equal(fast[k], full[k])
+    assert not np.array_equal(fast[3], full[3])   # (the five-slice iterates are really in use)
+    for c in range(n):
+        for k in (3, 4):   # theta, p after three steps
+            assert rel_err(fast[k][c], full[k][c]) < 1e-11, (c, k)
+            assert rel_err(fast[k][c], ref[k][c]) < 1e-9 and rel_err(full[k][c], ref[k][c]) < 1e-9, (c, k)
