@@ -30,12 +30,16 @@
 //   2^(cexp[a]+cexp[b]), the inverse of the equilibrated metric), because x' G^-1 x is a sum of O(1) terms whose two factors vary by
 //   the SQUARE of the column scales in opposite directions.  Then Q~ carries the CHAIN's exponent and Z~ the DATA ROW's, so h_n is
 //   accurate relative to max|Q~| max_a|x~_na|^2 for every (chain, row): |dh_n| <= S NP 2^(eq_c + ez_n + 4 - 8S), NP = D(D+1)/2.
+//   Inner iterates: at S = 6 the assemblies whose G only steers a fixed-point iterate (position iterates before the last, launch_assemble in
+//   rmhmc_hip.hip) use the S - 1 most significant slices of the same operands, i.e. the bounds above with S - 1 for THOSE matrices only; every
+//   G that enters a Hamiltonian, a leverage, rmhmc_metric or the last iterate has the full S (RMHMC_FLAG_INT8_INNER_FULL: all of them).
 //
 // Operand layout in HBM ("stage major": the tile one workgroup needs for one k-stage of 32 data rows is contiguous):
 //     Vs[S][nks][nCp][32]  int8     chains,       nCp = chains rounded up to 128
 //     Zs[S][nks][NPp][32]  int8     column pairs, NPp = D(D+1)/2 rounded up to the tile width
 // Workgroup = 2 x WN waves, wave tile 64 chains x 32*TN pairs, three LDS buffers filled by LDS-DMA, 32-byte rows with a one-bit
-// swizzle (i8_lds_off).
+// swizzle (i8_lds_off).  A slicing with S digits contains the one with S - 1 as its leading planes (balanced digits), which is what the
+// inner iterates and the S - 1 instantiations of the kernels use.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
