@@ -114,13 +114,43 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 //   RP_F : out0 = v_n, out2 = c_n, partial sums over the row split of the likelihood gradient
 //          X'(t - e^f/(1+e^f)) (rmhmc.py:100,140; a fourth small GEMM whose B operand is the accumulator
 //          layout of F, as in k_mompass) and of the log joint sum_n f t - log(1+e^f)   (rmhmc.py:167-168)
-// The naive exp/log forms are kept on purpose: they overflow exactly where the reference does.
+// p = 1 / (1 + e^-f) in the naive form, which saturates exactly where the reference does; the log joint and gradient terms follow from
+// p (softplus_sigmoid).
 // Row assignment inside a 16-row tile ("row-permuted"): MFMA row i of the F product is data row rm_perm16(i) = 4 (i & 3) + (i >> 2),
 // so that accumulator register r of lane l holds data row 4 (l>>4) + r and chain l&15: a lane's four values are four CONSECUTIVE
 // data rows.  The permuted A operand is still one 128-byte line per 16 lanes; the row vectors in natural layout (v, c, R) go out and
 // come in as one 32-byte access per lane, and the byte slices of v need no cross-lane transpose.  k_mompass and k_trvec use the same
 // assignment (the c tiles of k_rowpass<RP_F> are read by k_mompass<.., 2>).
 // ---------------------------------------------------------------------------------------------
+// log(1 + e^f) and e^f / (1 + e^f) of the log joint and its gradient (rmhmc.py:100,140,167-168) from p = 1 / (1 + e^-f), which the row
+// pass has at hand, instead of a second exp, an ocml log and a second divide (148 -> 77 fp64 instructions per data row in k_rowpass<RP_F>,
+// whose time is the fp64 VALU's):  e^f / (1 + e^f) = p,  log(1 + e^f) = max(f, 0) - log(y) with y = p (f >= 0) or 1 - p (f < 0), y in
+// [1/2, 1]; log(y) = k ln 2 + 2 atanh((m - 1) / (m + 1)) for m = y or 2 y in [sqrt(1/2), sqrt(2)) (|s| <= 0.1716: 11 odd terms to 1e-17).
+// Same error class as the naive forms (absolute 1e-16 on the softplus, 2e-16 on the sigmoid), and the same overflow behaviour: where
+// e^f overflows (f > 709.78) the reference gets log(inf) = inf and inf / inf = NaN, so do we.
+__device__ __forceinline__ void softplus_sigmoid(double f, double p, double& sp, double& sg) {
+  const double y = f >= 0.0 ? p : 1.0 - p;
+  const bool lo = y < 0.70710678118654752;
+  const double m = lo ? 2.0 * y : y;
+  const double d = m + 1.0;  // in [1.70, 2.42): plain Newton reciprocal, no scaling
+  double rc = __builtin_amdgcn_rcp(d);
+  rc = fma(fma(-d, rc, 1.0), rc, rc);
+  rc = fma(fma(-d, rc, 1.0), rc, rc);
+  const double sn = m - 1.0;  // exact
+  double sq = sn * rc;
+  sq = fma(fma(-d, sq, sn), rc, sq);  // s = sn / d, correctly rounded up to the last half ulp
+  const double s2 = sq * sq;
+  double pl = 2.0 / 21.0;
+  pl = fma(pl, s2, 2.0 / 19.0); pl = fma(pl, s2, 2.0 / 17.0); pl = fma(pl, s2, 2.0 / 15.0); pl = fma(pl, s2, 2.0 / 13.0);
+  pl = fma(pl, s2, 2.0 / 11.0); pl = fma(pl, s2, 2.0 / 9.0); pl = fma(pl, s2, 2.0 / 7.0); pl = fma(pl, s2, 2.0 / 5.0);
+  pl = fma(pl, s2, 2.0 / 3.0); pl = fma(pl, s2, 2.0);
+  const double logy = fma(sq, pl, lo ? -0.69314718055994531 : 0.0);
+  sp = fmax(f, 0.0) - logy;
+  sg = p;
+  if (f > 709.782712893384) { sp = __builtin_inf(); sg = __builtin_nan(""); }
+  if (f != f) sp = f;  // (fmax drops a NaN)
+}
+
 enum { RP_V = 0, RP_F = 1, RP_G = 2 };  // RP_G: as RP_F without the v / c row vectors (plain HMC)
 __device__ __forceinline__ int rm_perm16(int i) { return 4 * (i & 3) + (i >> 2); }
 
@@ -228,10 +258,11 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
       vv[r] = v;
       cc[r] = v * (1.0 - 2.0 * p);
       if (MODE != RP_V) {
-        const double ef = exp(f);
         const double tn = t4[r];
-        if (n < dd.M) lj += f * tn - log(1.0 + ef);
-        const double rn = tn - ef / (1.0 + ef);  // padded rows: x = 0, no contribution
+        double sp, sg;
+        softplus_sigmoid(f, p, sp, sg);
+        if (n < dd.M) lj += f * tn - sp;
+        const double rn = tn - sg;  // padded rows: x = 0, no contribution
 #pragma unroll
         for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rn, Gr[I], 0, 0, 0);
       }
