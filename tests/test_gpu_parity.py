@@ -634,3 +634,33 @@ def test_c_cache_and_graph_replay_do_not_change_results(hip, monkeypatch):
         assert np.array_equal(a, b)
     assert np.array_equal(base[1], nocache[1]) and np.array_equal(base[2], nocache[2])     # same transitions, same accept decisions
     assert rel_err(base[0], nocache[0]) < 1e-11
+
+
+@pytest.mark.parametrize("flags", [0, _capi.int8_metric_flags(6)])
+def test_log_joint_terms_saturate_like_the_reference(hip, oracle, flags):
+    """k_rowpass<RP_F> derives log(1 + e^f) and e^f / (1 + e^f) from p (softplus_sigmoid): where e^f overflows the reference gets
+    log(inf) = inf and inf / inf = NaN, where e^-f overflows it gets the finite limits; so must the kernel, value for value."""
+    M, D, n = 300, 40, 6
+    XX, t = synthetic_logreg(M, D, 2)
+    XX = XX.copy(); XX[:, 0] = 1.0
+    w = np.zeros((n, D))
+    w[0, 0] = 800.0      # every row f > 709.78: log joint -inf, gradient NaN
+    w[1, 0] = -800.0     # every row f < -709.78: finite
+    w[2, 0] = 700.0      # large but finite
+    w[3, 0] = -700.0
+    w[4] = 0.3 * np.random.RandomState(1).randn(D)
+    w[5, 1] = 50.0       # mixed signs, |f| up to a few hundred
+    out = {}
+    for name, lib, fl in (("hip", hip, flags), ("oracle", oracle, 0)):
+        with lib.context(M, D, n, flags=fl) as ctx:
+            ctx.set_data(XX, t, 100.0)
+            with np.errstate(all="ignore"):
+                out[name] = (ctx.log_posterior(w),) + ctx.metric(w)
+    lp_h, _, _, g_h = out["hip"]; lp_o, _, _, g_o = out["oracle"]
+    assert np.array_equal(np.isnan(lp_h), np.isnan(lp_o)) and np.array_equal(np.isinf(lp_h), np.isinf(lp_o))
+    assert np.array_equal(np.isnan(g_h), np.isnan(g_o))
+    ok = np.isfinite(lp_o)
+    assert ok[1:].all() and not ok[0]
+    assert np.abs(lp_h[ok] - lp_o[ok]).max() <= 1e-12 * np.abs(lp_o[ok]).max()
+    for c in np.nonzero(ok)[0]:
+        assert rel_err(g_h[c], g_o[c]) < 1e-12, c
