@@ -116,12 +116,67 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 //          layout of F, as in k_mompass) and of the log joint sum_n f t - log(1+e^f)   (rmhmc.py:167-168)
 // p = 1 / (1 + e^-f) in the naive form, which saturates exactly where the reference does; the log joint and gradient terms follow from
 // p (softplus_sigmoid).
-// Row assignment inside a 16-row tile ("row-permuted"): MFMA row i of the F product is data row rm_perm16(i) = 4 (i & 3) + (i >> 2),
-// so that accumulator register r of lane l holds data row 4 (l>>4) + r and chain l&15: a lane's four values are four CONSECUTIVE
-// data rows.  The permuted A operand is still one 128-byte line per 16 lanes; the row vectors in natural layout (v, c, R) go out and
-// come in as one 32-byte access per lane, and the byte slices of v need no cross-lane transpose.  k_mompass and k_trvec use the same
-// assignment (the c tiles of k_rowpass<RP_F> are read by k_mompass<.., 2>).
+// Row assignment: 32-row blocks of two interleaved 16-row MFMA tiles (see the loop below); a lane holds eight consecutive data rows
+// of its chain.  k_mompass and k_trvec use the same assignment (the c tiles of k_rowpass<RP_F> are read by k_mompass<.., 2>).
 // ---------------------------------------------------------------------------------------------
+typedef double d2 __attribute__((ext_vector_type(2)));
+// Q[j] (j < S): byte r = balanced base-256 digit j (least significant first) of N_r = rint(v_r 2^(8S + vexp)), r = 0..3.
+template <int S>
+__device__ __forceinline__ void slice_digits(const d4& vv, double vscale, double vmagic, int vsh, int& bad, unsigned (&Q)[S]) {
+  if constexpr (S <= 6) {
+    // Fast path (at most 48 bits).  N = sum_j d_j 256^j with balanced digits d_j in [-128, 127]  <=>  N + B, B = sum_j<S 128 256^j, has the
+    // UNSIGNED bytes d_j + 128.  One fma puts N + B into the mantissa of a double in [2^52, 2^53) (round to nearest even at ulp 1: the same
+    // rounding as rint), so the digits are the mantissa bytes xor 0x80; a 4 x 6 byte transpose (v_perm_b32) gives one dword per slice.
+    unsigned L[4], H[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double x = vv[r];
+      if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
+      const double z = fma(x, vscale, vmagic);
+      L[r] = (unsigned)__double2loint(z);
+      H[r] = (unsigned)__double2hiint(z);
+    }
+    const unsigned a = __builtin_amdgcn_perm(L[1], L[0], 0x05010400u), b2 = __builtin_amdgcn_perm(L[1], L[0], 0x07030602u);
+    const unsigned c = __builtin_amdgcn_perm(L[3], L[2], 0x05010400u), d2_ = __builtin_amdgcn_perm(L[3], L[2], 0x07030602u);
+    unsigned Qf[6];
+    Qf[0] = __builtin_amdgcn_perm(c, a, 0x05040100u) ^ 0x80808080u;
+    Qf[1] = __builtin_amdgcn_perm(c, a, 0x07060302u) ^ 0x80808080u;
+    Qf[2] = __builtin_amdgcn_perm(d2_, b2, 0x05040100u) ^ 0x80808080u;
+    Qf[3] = __builtin_amdgcn_perm(d2_, b2, 0x07060302u) ^ 0x80808080u;
+    const unsigned ah = __builtin_amdgcn_perm(H[1], H[0], 0x05010400u), ch = __builtin_amdgcn_perm(H[3], H[2], 0x05010400u);
+    Qf[4] = __builtin_amdgcn_perm(ch, ah, 0x05040100u) ^ 0x80808080u;
+    Qf[5] = __builtin_amdgcn_perm(ch, ah, 0x07060302u) ^ 0x80808080u;
+#pragma unroll
+    for (int j = 0; j < S; ++j) Q[j] = Qf[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < S; ++j) Q[j] = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double x = vv[r];
+      if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
+      // N = rint(x 2^(8S)) < 2^(8S-2) as two 32-bit words split at bit 24 (all in exact fp64 / int32 arithmetic: no 64-bit
+      // integer emulation): three balanced digits from the low word, the carry and up to four more from the high word
+      const double y = rint(ldexp(x, 8 * S + vsh));
+      const double yh = floor(y * 5.9604644775390625e-08);  // 2^-24
+      int lo = (int)(y - yh * 16777216.0), hi = (int)yh;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int bt = (int)(signed char)(lo & 0xFF);
+        Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
+        lo = (lo - bt) >> 8;
+      }
+      hi += lo;  // carry out of the low word
+#pragma unroll
+      for (int j = 3; j < S; ++j) {
+        const int bt = (int)(signed char)(hi & 0xFF);
+        Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
+        hi = (hi - bt) >> 8;
+      }
+    }
+  }
+}
+
 // log(1 + e^f) and e^f / (1 + e^f) of the log joint and its gradient (rmhmc.py:100,140,167-168) from p = 1 / (1 + e^-f), which the row
 // pass has at hand, instead of a second exp, an ocml log and a second divide (148 -> 77 fp64 instructions per data row in k_rowpass<RP_F>,
 // whose time is the fp64 VALU's):  e^f / (1 + e^f) = p,  log(1 + e^f) = max(f, 0) - log(y) with y = p (f >= 0) or 1 - p (f < 0), y in
@@ -170,7 +225,7 @@ struct VSlice {
 // I8S: 0 = fp64 row vectors, else the number of byte slices (compile time: the slicing code is straight-line)
 // (the slicing RP_F variant takes 190 VGPRs = 2 waves per SIMD; asked for 3 / 4 waves it spills: rowpass 2.51 -> 2.99 / 3.57 ms per step)
 template <int NB, int MODE, int I8S = 0>
-__global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
+__global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
                                                  double* __restrict__ out2, double* __restrict__ gpart,
                                                  double* __restrict__ ljl_part, VSlice vs = VSlice{}, d4* __restrict__ ctile = nullptr) {
@@ -211,46 +266,41 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
     for (int j = 0; j < I8S && j < 6; ++j) bsum += ldexp(128.0, 8 * j);
     vmagic += bsum;
   }
-  const int nb16 = dd.Mp / 16;
-  const int per = (nb16 + nsplit - 1) / nsplit;
-  const int b0 = split * per, b1 = min(nb16, b0 + per);
-  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + rm_perm16(ci);  // A: X[n0+perm(ci)][4kk+rr]
-  const double* __restrict__ xr_p = dd.Xr + (size_t)(4 * rr) * DP + NB * ci;      // A of the gradient product: X[n0+4rr+r][NB ci+I]
+  // 32-row blocks = two 16-row MFMA tiles "A" and "B" whose rows interleave: lane (rr, ci) holds, for chain ci, data rows
+  // n0 + 8 rr + 2 r (tile A, accumulator register r) and n0 + 8 rr + 2 r + 1 (tile B), i.e. EIGHT consecutive rows.  MFMA row i of
+  // tile A is data row n0 + 2 rm_perm16(i), of tile B the next one, so ONE 16-byte load per lane brings the F operands of both tiles
+  // (16 lanes: 256 contiguous bytes); a slice plane gets 8 bytes per lane = the chain's whole 32-byte stage row from four lanes, 512
+  // contiguous bytes per store instruction; row vectors in natural layout move as 64 contiguous bytes per lane.  (With 16-row tiles and
+  // 4-byte slice stores the row pass was bound by its memory instructions: without the stores 466 -> 299 us, without the loads -> 327.)
+  const int nb16 = dd.Mp / 16, nb32 = dd.Mp / 32;
+  const int per = (nb32 + nsplit - 1) / nsplit;
+  const int B0 = split * per, B1 = min(nb32, B0 + per);
+  // (wave-uniform base + one 32-bit per-lane byte offset: the loads take the scalar-base form, no 64-bit address registers per operand)
+  const unsigned xt_off = (unsigned)(rr * dd.Mp + 2 * rm_perm16(ci)) * 8u;  // F operands: X[n0 + 2 perm(ci) + {0,1}][4kk+rr]
+  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + 2 * rm_perm16(ci);
+  const unsigned xr_off = (unsigned)(8 * rr * DP + NB * ci) * 8u;           // gradient operands: X[n0 + 8rr + k][NB ci + I]
   double lj = 0.0;
   int bad = 0;
   d4 Gr[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Gr[I] = (d4){0.0, 0.0, 0.0, 0.0};
-  // Software pipeline as in k_mompass: the A operand of the next tile's F product is requested before the matrix instructions of the
-  // current tile (two register sets), the A operand of the gradient product at the start of its own tile.  Not for the variants that
-  // also cut v into byte slices (I8): measured again with the straight-line slicing code, rowpass 2.49 ms per step without, 2.71 with
-  // the pipeline in RP_F, 2.51 with it in RP_V (fp64 variants: 2.33 -> 2.06).
-  constexpr bool PIPE = !I8;
-  double A0[KK], A1[KK];
-  auto load_a = [&](double (&A)[KK], int b) {
+  // One register set for the F operands: the next block's are requested as soon as this block's F products have consumed them, and
+  // land behind the element-wise work and the gradient products.
+  d2 A[KK];
+  auto load_a = [&](int B, int k0, int k1) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + b * 16];
+    for (int kk = 0; kk < KK; ++kk)
+      if (kk >= k0 && kk < k1) {
+        if (MODE == RP_V) A[kk] = *(const d2*)(xt_p + (size_t)(4 * kk) * dd.Mp + B * 32);  // (registers to spare; the 16 scalar bases would spill SGPRs)
+        else A[kk] = *(const d2*)((const char*)(dd.Xt + (size_t)(4 * kk) * dd.Mp + (size_t)B * 32) + xt_off);
+      }
   };
-  auto tile = [&](const double (&A)[KK], int b) {
-    const int n0 = b * 16;
-    double xb[4][NB];
-    if (MODE != RP_V) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + r) * DP + I];
-    }
-    if (PIPE) __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above the products below)
-    d4 F = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
-    d4 vv, cc = (d4){0.0, 0.0, 0.0, 0.0};
-    const int nl = n0 + 4 * rr;  // the lane's four data rows nl .. nl+3
-    d4 t4 = (d4){0.0, 0.0, 0.0, 0.0};
-    if (MODE != RP_V) t4 = *(const d4*)(dd.t + nl);
+  auto xrow = [&](int n, int I) { return *(const double*)((const char*)(dd.Xr + (size_t)n * DP + I) + xr_off); };
+  // element-wise part of one tile: F -> v, c (and softplus / residual); rows nl + 2 r + h
+  auto elem = [&](const d4& F, const d4& tq, int nl, int h, d4& vv, d4& cc, d4& rn) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = nl + r;
+      const int n = nl + 2 * r + h;
       const double f = F[r];
       const double em = exp(-f);
       const double p = 1.0 / (1.0 + em);
@@ -258,102 +308,103 @@ __global__ __launch_bounds__(256) void k_rowpass(DevData dd, int n_chains, int n
       vv[r] = v;
       cc[r] = v * (1.0 - 2.0 * p);
       if (MODE != RP_V) {
-        const double tn = t4[r];
+        const double tn = tq[r];
         double sp, sg;
         softplus_sigmoid(f, p, sp, sg);
         if (n < dd.M) lj += f * tn - sp;
-        const double rn = tn - sg;  // padded rows: x = 0, no contribution
-#pragma unroll
-        for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rn, Gr[I], 0, 0, 0);
-      }
-    }
-    if (live) {  // row vectors in natural layout: 32 contiguous bytes per lane
-      const size_t o = (size_t)cj * dd.Mp + nl;
-      if (MODE != RP_G && !I8) *(d4*)(out0 + o) = vv;
-      if (MODE == RP_F) *(d4*)(out2 + o) = cc;
-      // c in the accumulator layout, for k_mompass<NB, 2> at the same position (same chain group / row block / lane mapping)
-      if (MODE == RP_F && ctile) ctile[((size_t)(c0 >> 4) * nb16 + b) * 64 + lane] = cc;
-    }
-    if constexpr (I8 && MODE != RP_G) {
-      // byte k of Q[j] = digit j (least significant first) of rint(v 2^(8S + vexp)) for the lane's row nl + k: one dword of slice
-      // plane S-1-j; only live chains and stages inside the slice planes are stored
-      unsigned Q[I8S > 0 ? I8S : 1];
-      if constexpr (I8S <= 6) {
-        // Fast path (at most 48 bits).  N = rint(x 2^k) = sum_j d_j 256^j with balanced digits d_j in [-128, 127]  <=>  N + B, B = sum_j<S
-        // 128 256^j, has the UNSIGNED bytes d_j + 128.  One fma puts N + B into the mantissa of a double in [2^52, 2^53) (round to
-        // nearest even at ulp 1: the same rounding as rint), so the digits are the mantissa bytes xor 0x80; a 4 x 6 byte transpose
-        // (v_perm_b32) turns the four rows' words into one dword per slice.
-        unsigned L[4], H[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double x = vv[r];
-          if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
-          const double z = fma(x, vscale, vmagic);
-          L[r] = (unsigned)__double2loint(z);
-          H[r] = (unsigned)__double2hiint(z);
-        }
-        const unsigned a = __builtin_amdgcn_perm(L[1], L[0], 0x05010400u), b2 = __builtin_amdgcn_perm(L[1], L[0], 0x07030602u);
-        const unsigned c = __builtin_amdgcn_perm(L[3], L[2], 0x05010400u), d2 = __builtin_amdgcn_perm(L[3], L[2], 0x07030602u);
-        unsigned Qf[6];
-        Qf[0] = __builtin_amdgcn_perm(c, a, 0x05040100u) ^ 0x80808080u;
-        Qf[1] = __builtin_amdgcn_perm(c, a, 0x07060302u) ^ 0x80808080u;
-        Qf[2] = __builtin_amdgcn_perm(d2, b2, 0x05040100u) ^ 0x80808080u;
-        Qf[3] = __builtin_amdgcn_perm(d2, b2, 0x07060302u) ^ 0x80808080u;
-        const unsigned ah = __builtin_amdgcn_perm(H[1], H[0], 0x05010400u), ch = __builtin_amdgcn_perm(H[3], H[2], 0x05010400u);
-        Qf[4] = __builtin_amdgcn_perm(ch, ah, 0x05040100u) ^ 0x80808080u;
-        Qf[5] = __builtin_amdgcn_perm(ch, ah, 0x07060302u) ^ 0x80808080u;
-#pragma unroll
-        for (int j = 0; j < I8S; ++j) Q[j] = Qf[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < I8S; ++j) Q[j] = 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double x = vv[r];
-          if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
-          // N = rint(x 2^(8S)) < 2^(8S-2) as two 32-bit words split at bit 24 (all in exact fp64 / int32 arithmetic: no 64-bit
-          // integer emulation): three balanced digits from the low word, the carry and up to four more from the high word
-          const double y = rint(ldexp(x, 8 * I8S + vsh));
-          const double yh = floor(y * 5.9604644775390625e-08);  // 2^-24
-          int lo = (int)(y - yh * 16777216.0), hi = (int)yh;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const int bt = (int)(signed char)(lo & 0xFF);
-            Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
-            lo = (lo - bt) >> 8;
-          }
-          hi += lo;  // carry out of the low word
-#pragma unroll
-          for (int j = 3; j < I8S; ++j) {
-            const int bt = (int)(signed char)(hi & 0xFF);
-            Q[j] |= (unsigned)(bt & 0xFF) << (8 * r);
-            hi = (hi - bt) >> 8;
-          }
-        }
-      }
-      const int ks = n0 >> 5;
-      if (live && ks < vs.nks) {
-        int8_t* vp = vs.Vs + ((size_t)ks * vs.nCp + cj) * 32 + (n0 & 31) + 4 * rr;
-        const size_t plane = (size_t)vs.nks * vs.nCp * 32;
-#pragma unroll
-        for (int j = 0; j < I8S; ++j) *(unsigned*)(vp + (size_t)(I8S - 1 - j) * plane) = Q[j];
+        rn[r] = tn - sg;  // padded rows: x = 0, no contribution
       }
     }
   };
-  if (PIPE) {
-    if (b0 < b1) load_a(A0, b0);
-    for (int b = b0; b < b1; b += 2) {
-      if (b + 1 < b1) load_a(A1, b + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      tile(A0, b);
-      if (b + 2 < b1) load_a(A0, b + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (b + 1 < b1) tile(A1, b + 1);
+  if (B0 < B1) load_a(B0, 0, KK);
+  for (int B = B0; B < B1; ++B) {
+    const int n0 = 32 * B, nl = n0 + 8 * rr;  // the lane's eight data rows nl .. nl+7
+    // gradient operands of a tile are requested just before its element-wise work and land behind it; the two tiles are worked off
+    // one after the other to keep the live registers of the exp / softplus code low
+    double xa[4][NB], xb[4][NB];
+    d4 FA = (d4){0.0, 0.0, 0.0, 0.0}, FB = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      // (RP_F: w is read again for every block - 512 cache-resident bytes per wave - instead of living in 32 registers the whole
+      // launch: with them the kernel needs ~290 registers and spills, or runs one wave per SIMD, 1.34 ms against 1.0)
+      double wk;
+      if constexpr (MODE == RP_F) wk = *(const volatile double*)(wq + (size_t)cj * DP + 4 * kk + rr);
+      else wk = Wb[kk];
+      FA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, wk, FA, 0, 0, 0);
+      FB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, wk, FB, 0, 0, 0);
     }
-  } else {
-    for (int b = b0; b < b1; ++b) {
-      load_a(A0, b);
-      tile(A0, b);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == RP_V && B + 1 < B1) load_a(B + 1, 0, KK);  // (RP_F / RP_G: in halves behind the tiles' work, for the registers)
+    d4 tA = (d4){0.0, 0.0, 0.0, 0.0}, tB = tA;
+    if (MODE != RP_V) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) xa[r][I] = xrow(n0 + 2 * r, I);
+      const d4 t0 = *(const d4*)(dd.t + nl), t1 = *(const d4*)(dd.t + nl + 4);
+      tA = (d4){t0[0], t0[2], t1[0], t1[2]};
+      tB = (d4){t0[1], t0[3], t1[1], t1[3]};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    d4 vA, cA, rnA = (d4){0.0, 0.0, 0.0, 0.0}, vB, cB, rnB = rnA;
+    elem(FA, tA, nl, 0, vA, cA, rnA);
+    if (MODE != RP_V) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[r][I], rnA[r], Gr[I], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE != RP_V) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) xb[r][I] = xrow(n0 + 2 * r + 1, I);
+      if (B + 1 < B1) load_a(B + 1, 0, KK / 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    elem(FB, tB, nl, 1, vB, cB, rnB);
+    if (MODE != RP_V) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Gr[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rnB[r], Gr[I], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (B + 1 < B1) load_a(B + 1, KK / 2, KK);
+    }
+    if (live) {  // row vectors in natural layout: 64 contiguous bytes per lane
+      const size_t o = (size_t)cj * dd.Mp + nl;
+      if (MODE != RP_G && !I8) {
+        *(d4*)(out0 + o) = (d4){vA[0], vB[0], vA[1], vB[1]};
+        *(d4*)(out0 + o + 4) = (d4){vA[2], vB[2], vA[3], vB[3]};
+      }
+      if (MODE == RP_F) {
+        *(d4*)(out2 + o) = (d4){cA[0], cB[0], cA[1], cB[1]};
+        *(d4*)(out2 + o + 4) = (d4){cA[2], cB[2], cA[3], cB[3]};
+        // c in the accumulator layout, for k_mompass<NB, 2> at the same position (same chain group / block / lane / tile mapping)
+        if (ctile) {
+          ctile[((size_t)(c0 >> 4) * nb16 + 2 * B) * 64 + lane] = cA;
+          ctile[((size_t)(c0 >> 4) * nb16 + 2 * B + 1) * 64 + lane] = cB;
+        }
+      }
+    }
+    if constexpr (I8 && MODE != RP_G) {
+      // QA[j] / QB[j]: byte r = digit j (least significant first) of rint(v 2^(8S + vexp)) for the tile's element r; interleaved
+      // they are the 8 bytes of slice plane S-1-j for rows nl .. nl+7.  Only live chains and stages inside the planes are stored.
+      unsigned QA[I8S], QB[I8S];
+      slice_digits<I8S>(vA, vscale, vmagic, vsh, bad, QA);
+      slice_digits<I8S>(vB, vscale, vmagic, vsh, bad, QB);
+      if (live && B < vs.nks) {
+        int8_t* vp = vs.Vs + ((size_t)B * vs.nCp + cj) * 32 + 8 * rr;
+        const size_t plane = (size_t)vs.nks * vs.nCp * 32;
+#pragma unroll
+        for (int j = 0; j < I8S; ++j) {
+          uint2 q;
+          q.x = __builtin_amdgcn_perm(QB[j], QA[j], 0x05010400u);  // A0 B0 A1 B1
+          q.y = __builtin_amdgcn_perm(QB[j], QA[j], 0x07030602u);  // A2 B2 A3 B3
+          *(uint2*)(vp + (size_t)(I8S - 1 - j) * plane) = q;
+        }
+      }
     }
   }
   if (I8 && MODE != RP_G && bad && live) atomicOr(&vs.vbad[cj], 1);
@@ -544,7 +595,7 @@ __global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, 
 //   CM 2  c loaded: no F product, no exp                             (the other K-1 iterations - same w -, and the pass of the point
 //         evaluation rmhmc.py:158-161, whose row pass k_rowpass<RP_F> has just stored c for the same w in the same layout)
 template <int NB, int CM>
-__global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int nsplit, const double* __restrict__ wq,
+__global__ __launch_bounds__(256, 2) void k_mompass(DevData dd, int n_chains, int nsplit, const double* __restrict__ wq,
                                                  const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
@@ -560,63 +611,108 @@ __global__ __launch_bounds__(256) void k_mompass(DevData dd, int n_chains, int n
     if (CM != 2) Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
     Ub[kk] = uq[(size_t)cj * DP + 4 * kk + rr];
   }
-  const int nb16 = dd.Mp / 16;
-  const int per = (nb16 + nsplit - 1) / nsplit;
-  const int b0 = split * per, b1 = min(nb16, b0 + per);
+  // 32-row blocks of two interleaved 16-row tiles A / B, exactly as in k_rowpass (whose c tiles CM = 2 reads): lane (rr, ci) holds data
+  // rows n0 + 8 rr + 2 r (A) and n0 + 8 rr + 2 r + 1 (B); one 16-byte load per lane brings the F / S operands of both tiles.
+  const int nb16 = dd.Mp / 16, nb32 = dd.Mp / 32;
+  const int per = (nb32 + nsplit - 1) / nsplit;
+  const int B0 = split * per, B1 = min(nb32, B0 + per);
   d4* __restrict__ ct = ctile + (size_t)(c0 >> 4) * nb16 * 64 + lane;
   d4 Q[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Q[I] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + rm_perm16(ci);   // A of F,S: X[n0+perm(ci)][4kk+rr] (row-permuted tile, see k_rowpass)
-  const double* __restrict__ xr_p = dd.Xr + (size_t)(4 * rr) * DP + NB * ci;       // A of Q  : X[n0+4rr+r][NB*ci+I]
-  // Software pipeline over the 16-row tiles: the A operand of F / S (and c) of the NEXT tile is requested before the matrix instructions
-  // of the current one, and the A operand of Q of the current tile at its start, behind the F / S products.  Left to itself the
-  // compiler keeps two A registers in flight and puts an s_waitcnt vmcnt(1) in front of every MFMA: a wave then pays the L2 latency
-  // sixteen times per tile and only the four waves per SIMD hide some of it (59 % MFMA busy).
-  double A0[KK], A1[KK];
-  d4 cc0, cc1;
-  auto load_a = [&](double (&A)[KK], d4& cc, int b) {
+  const unsigned xt_off = (unsigned)(rr * dd.Mp + 2 * rm_perm16(ci)) * 8u;  // A of F,S: X[n0 + 2 perm(ci) + {0,1}][4kk+rr]  (scalar base +
+  const unsigned xr_off = (unsigned)(8 * rr * DP + NB * ci) * 8u;           // A of Q  : X[n0 + 8rr + k][NB*ci+I]            32-bit lane offset)
+  // One register set for the F / S operands: the next block's (and its c tiles) are requested as soon as this block's F / S products
+  // have consumed them and land behind the 32 MFMAs of the Q products.  (Left to itself the compiler keeps two operand registers in
+  // flight and puts an s_waitcnt vmcnt(1) in front of every MFMA: 59 % MFMA busy.)
+  d2 A[KK];
+  d4 ccA = (d4){0.0, 0.0, 0.0, 0.0}, ccB = ccA;
+  auto load_a = [&](int B, int k0, int k1) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) A[kk] = xt_p[(size_t)(4 * kk) * dd.Mp + b * 16];
-    if (CM == 2) cc = ct[(size_t)b * 64];
+    for (int kk = 0; kk < KK; ++kk)
+      if (kk >= k0 && kk < k1) A[kk] = *(const d2*)((const char*)(dd.Xt + (size_t)(4 * kk) * dd.Mp + (size_t)B * 32) + xt_off);
   };
-  auto tile = [&](const double (&A)[KK], d4 cc, int b) {
-    double xb[4][NB];
+  auto xrow = [&](int n, int I) { return *(const double*)((const char*)(dd.Xr + (size_t)n * DP + I) + xr_off); };
+  if (B0 < B1) {
+    load_a(B0, 0, KK);
+    if (CM == 2) { ccA = ct[(size_t)(2 * B0) * 64]; ccB = ct[(size_t)(2 * B0 + 1) * 64]; }
+  }
+  for (int B = B0; B < B1; ++B) {
+    const int n0 = 32 * B;
+    // Q operands of tile A now (they land behind the F / S products), of tile B behind those products (they land behind tile A's Q
+    // products)
+    double xa[4][NB], xb[4][NB];
+    if (CM == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) xa[r][I] = xrow(n0 + 2 * r, I);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    d4 FA = (d4){0.0, 0.0, 0.0, 0.0}, FB = FA, SA = FA, SB = FA;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (CM != 2) {
+        FA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, Wb[kk], FA, 0, 0, 0);
+        FB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, Wb[kk], FB, 0, 0, 0);
+      }
+      SA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, Ub[kk], SA, 0, 0, 0);
+      SB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, Ub[kk], SB, 0, 0, 0);
+    }
+    d4 cA = ccA, cB = ccB;
+    __builtin_amdgcn_sched_barrier(0);
+    // (with the exp of c in the pass - CM 0 / 1 - the Q operands of a tile are requested just before its c, to stay within 256 registers)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(b * 16 + r) * DP + I];
-    __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above the products below)
-    d4 F = (d4){0.0, 0.0, 0.0, 0.0}, S = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      if (CM != 2) F = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Wb[kk], F, 0, 0, 0);
-      S = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk], Ub[kk], S, 0, 0, 0);
-    }
+      for (int I = 0; I < NB; ++I) {
+        if (CM == 2) xb[r][I] = xrow(n0 + 2 * r + 1, I);
+        else xa[r][I] = xrow(n0 + 2 * r, I);
+      }
+    if (B + 1 < B1) load_a(B + 1, 0, KK / 2);  // (the other half once tile A's Q operands are used up: registers)
+    __builtin_amdgcn_sched_barrier(0);
     if (CM != 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double em = exp(-F[r]);
-        const double p = 1.0 / (1.0 + em);
-        cc[r] = p * (1.0 - p) * (1.0 - 2.0 * p);
+        const double ea = exp(-FA[r]);
+        const double pa = 1.0 / (1.0 + ea);
+        cA[r] = pa * (1.0 - pa) * (1.0 - 2.0 * pa);
       }
-      if (CM == 1) ct[(size_t)b * 64] = cc;
+      if (CM == 1) ct[(size_t)(2 * B) * 64] = cA;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double R = cc[r] * S[r] * S[r];
+      const double RA = cA[r] * SA[r] * SA[r];
 #pragma unroll
-      for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], R, Q[I], 0, 0, 0);
+      for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[r][I], RA, Q[I], 0, 0, 0);
     }
-  };
-  if (b0 < b1) load_a(A0, cc0, b0);
-  for (int b = b0; b < b1; b += 2) {
-    if (b + 1 < b1) load_a(A1, cc1, b + 1);
     __builtin_amdgcn_sched_barrier(0);
-    tile(A0, cc0, b);
-    if (b + 2 < b1) load_a(A0, cc0, b + 2);
+    if (CM != 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) xb[r][I] = xrow(n0 + 2 * r + 1, I);
+    }
+    if (B + 1 < B1) {
+      load_a(B + 1, KK / 2, KK);
+      if (CM == 2) { ccA = ct[(size_t)(2 * B + 2) * 64]; ccB = ct[(size_t)(2 * B + 3) * 64]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if (b + 1 < b1) tile(A1, cc1, b + 1);
+    if (CM != 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double eb = exp(-FB[r]);
+        const double pb = 1.0 / (1.0 + eb);
+        cB[r] = pb * (1.0 - pb) * (1.0 - 2.0 * pb);
+      }
+      if (CM == 1) ct[(size_t)(2 * B + 1) * 64] = cB;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double RB = cB[r] * SB[r] * SB[r];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], RB, Q[I], 0, 0, 0);
+    }
   }
   if (c0 + ci < n_chains) {
     double* __restrict__ out = qpart + ((size_t)split * n_chains + c0 + ci) * DP;
@@ -1471,26 +1567,27 @@ __global__ __launch_bounds__(256) void k_trvec(DevData dd, int n_chains, int nsp
   const int split = blockIdx.y;
   const int rr = lane >> 4, ci = lane & 15;
   const int cj = min(c0 + ci, n_chains - 1);
-  const int nb16 = dd.Mp / 16;
-  const int per = (nb16 + nsplit - 1) / nsplit;
-  const int b0 = split * per, b1 = min(nb16, b0 + per);
-  const double* __restrict__ xr_p = dd.Xr + (size_t)(4 * rr) * DP + NB * ci;  // (row-permuted tile: the lane's rows are n0+4rr .. +3)
-  const double* __restrict__ rp = R + (size_t)cj * dd.Mp + 4 * rr;
+  // (32-row blocks, eight consecutive data rows per lane as in k_rowpass; the sum over rows does not care which tile a row is in)
+  const int nb32 = dd.Mp / 32;
+  const int per = (nb32 + nsplit - 1) / nsplit;
+  const int B0 = split * per, B1 = min(nb32, B0 + per);
+  const double* __restrict__ xr_p = dd.Xr + (size_t)(8 * rr) * DP + NB * ci;
+  const double* __restrict__ rp = R + (size_t)cj * dd.Mp + 8 * rr;
   d4 T[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) T[I] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int b = b0; b < b1; ++b) {
-    const int n0 = b * 16;
-    double xb[4][NB];
-    const d4 rv = *(const d4*)(rp + n0);  // 32 contiguous bytes per lane
+  for (int B = B0; B < B1; ++B) {
+    const int n0 = 32 * B;
+    const d4 r0 = *(const d4*)(rp + n0), r1 = *(const d4*)(rp + n0 + 4);  // 64 contiguous bytes per lane
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 8; ++k) {
+      double xb[NB];
 #pragma unroll
-      for (int I = 0; I < NB; ++I) xb[r][I] = xr_p[(size_t)(n0 + r) * DP + I];
+      for (int I = 0; I < NB; ++I) xb[I] = xr_p[(size_t)(n0 + k) * DP + I];
+      const double rv = k < 4 ? r0[k & 3] : r1[k & 3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], rv[r], T[I], 0, 0, 0);
+      for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[I], rv, T[I], 0, 0, 0);
+    }
   }
   if (c0 + ci < n_chains) {
     double* __restrict__ out = trpart + ((size_t)split * n_chains + c0 + ci) * DP;
