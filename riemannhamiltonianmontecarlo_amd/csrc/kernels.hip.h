@@ -379,9 +379,11 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
         *(d4*)(out0 + o + 4) = (d4){vA[2], vB[2], vA[3], vB[3]};
       }
       if (MODE == RP_F) {
-        *(d4*)(out2 + o) = (d4){cA[0], cB[0], cA[1], cB[1]};
-        *(d4*)(out2 + o + 4) = (d4){cA[2], cB[2], cA[3], cB[3]};
-        // c in the accumulator layout, for k_mompass<NB, 2> at the same position (same chain group / block / lane / tile mapping)
+        if (out2) {  // (null on the int8 path with c tiles: k_trvec takes c from the tiles)
+          *(d4*)(out2 + o) = (d4){cA[0], cB[0], cA[1], cB[1]};
+          *(d4*)(out2 + o + 4) = (d4){cA[2], cB[2], cA[3], cB[3]};
+        }
+        // c in the accumulator layout, for k_mompass<NB, 2> / k_trvec at the same position (same chain group / block / lane / tile mapping)
         if (ctile) {
           ctile[((size_t)(c0 >> 4) * nb16 + 2 * B) * 64 + lane] = cA;
           ctile[((size_t)(c0 >> 4) * nb16 + 2 * B + 1) * 64 + lane] = cB;
@@ -1555,11 +1557,13 @@ __global__ __launch_bounds__(64) void k_hmc_end(int D, int DP, Chains ch, IterPa
 }
 
 // ---------------------------------------------------------------------------------------------
-// trace term from per-row weights: tr_d = sum_n R[c][n] x_nd (R = c_n h_n written by k_leverage_i8).  Same MFMA mapping as the
+// trace term from per-row weights: tr_d = sum_n R[c][n] x_nd (R = c_n h_n written by k_leverage_i8, or h_n alone with c_n taken here
+// from the c tiles of the row pass: then neither the row pass writes nor the leverage GEMM's epilogue reads a natural-layout c).  Same MFMA mapping as the
 // gradient product of k_rowpass: 16 chains per wave, row splits, partial sums to trpart (summed by k_reduce_tr).
 // ---------------------------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(256) void k_trvec(DevData dd, int n_chains, int nsplit, const double* __restrict__ R, double* __restrict__ trpart) {
+__global__ __launch_bounds__(256) void k_trvec(DevData dd, int n_chains, int nsplit, const double* __restrict__ R, double* __restrict__ trpart,
+                                               const d4* __restrict__ ctile = nullptr) {
   constexpr int DP = 16 * NB;
   const int lane = threadIdx.x & 63;
   const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
@@ -1578,7 +1582,12 @@ __global__ __launch_bounds__(256) void k_trvec(DevData dd, int n_chains, int nsp
   for (int I = 0; I < NB; ++I) T[I] = (d4){0.0, 0.0, 0.0, 0.0};
   for (int B = B0; B < B1; ++B) {
     const int n0 = 32 * B;
-    const d4 r0 = *(const d4*)(rp + n0), r1 = *(const d4*)(rp + n0 + 4);  // 64 contiguous bytes per lane
+    d4 r0 = *(const d4*)(rp + n0), r1 = *(const d4*)(rp + n0 + 4);  // 64 contiguous bytes per lane
+    if (ctile) {  // R holds h alone; c comes in the tile layout of k_rowpass<RP_F>: tile 2B = rows nl + 2r, tile 2B+1 = rows nl + 2r + 1
+      const d4 cA = ctile[((size_t)(c0 >> 4) * (dd.Mp / 16) + 2 * B) * 64 + lane], cB = ctile[((size_t)(c0 >> 4) * (dd.Mp / 16) + 2 * B + 1) * 64 + lane];
+      r0 *= (d4){cA[0], cB[0], cA[1], cB[1]};
+      r1 *= (d4){cA[2], cB[2], cA[3], cB[3]};
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       double xb[NB];

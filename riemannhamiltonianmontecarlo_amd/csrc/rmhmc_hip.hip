@@ -231,8 +231,9 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
     if (ctx->i8 && MODE != RP_G) {  // int8 metric path: v goes out as byte slices (no fp64 row vector, no k_vsplit)
       (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
       const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
+      // (with c tiles nobody reads a natural-layout c on this path: k_mompass and k_trvec take the tiles)
       I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                                      out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
+                                                      g.ctile ? nullptr : out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
       return;
     }
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
@@ -294,14 +295,14 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
   if (g.ksplit_l > 1) {
     const size_t plane = (size_t)g.n * ctx->Mp;
     hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_l), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp, ctx->i8_NRp,
-                       ctx->i8_nkp, 0, ctx->i8_nkp, 0, ctx->big ? 0 : 1, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale, g.ch.rv2, g.Rpart, plane);
+                       ctx->i8_nkp, 0, ctx->i8_nkp, 0, (ctx->big || g.ctile) ? 0 : 1, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale, g.ch.rv2, g.Rpart, plane);
     hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.rv0, g.Rpart, g.ksplit_l, plane, plane);
     return;
   }
   for (int kp0 = 0; kp0 < ctx->i8_nkp; kp0 += ctx->i8_chunk) {
     const int nk = std::min(ctx->i8_chunk, ctx->i8_nkp - kp0);
     hipLaunchKernelGGL((k_leverage_i8<S, WN, TN>), dim3(nblk), dim3(128 * WN), lds, st, g.Qs, ctx->d_Zt, g.nCp,
-                       ctx->i8_NRp, ctx->i8_nkp, kp0, nk, kp0 > 0 ? 1 : 0, ctx->big ? 0 : 1, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale,
+                       ctx->i8_NRp, ctx->i8_nkp, kp0, nk, kp0 > 0 ? 1 : 0, (ctx->big || g.ctile) ? 0 : 1, g.n, ctx->Mp, g.ch.phase, g.qscale, ctx->d_zscale,
                        g.ch.rv2, g.ch.rv0, (size_t)0);
   }
 }
@@ -380,7 +381,7 @@ void launch_leverage(rmhmc_ctx* ctx, Group& g) {
         return;
       }
       dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
-      NB_SWITCH(ctx, hipLaunchKernelGGL((k_trvec<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.rv0, g.ch.gpart));
+      NB_SWITCH(ctx, hipLaunchKernelGGL((k_trvec<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.rv0, g.ch.gpart, (const d4*)g.ctile));
     });
     launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
       hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
