@@ -224,7 +224,8 @@ struct VSlice {
 };
 // I8S: 0 = fp64 row vectors, else the number of byte slices (compile time: the slicing code is straight-line)
 // (the slicing RP_F variant takes 190 VGPRs = 2 waves per SIMD; asked for 3 / 4 waves it spills: rowpass 2.51 -> 2.99 / 3.57 ms per step)
-template <int NB, int MODE, int I8S = 0>
+// CN: RP_F writes c in natural layout to out2 (off on the int8 path when c tiles are kept: its consumers take the tiles)
+template <int NB, int MODE, int I8S = 0, bool CN = true>
 __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
                                                  double* __restrict__ out2, double* __restrict__ gpart,
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
         *(d4*)(out0 + o + 4) = (d4){vA[2], vB[2], vA[3], vB[3]};
       }
       if (MODE == RP_F) {
-        if (out2) {  // (null on the int8 path with c tiles: k_trvec takes c from the tiles)
+        if constexpr (CN) {
           *(d4*)(out2 + o) = (d4){cA[0], cB[0], cA[1], cB[1]};
           *(d4*)(out2 + o + 4) = (d4){cA[2], cB[2], cA[3], cB[3]};
         }

@@ -232,8 +232,13 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
       (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
       const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
       // (with c tiles nobody reads a natural-layout c on this path: k_mompass and k_trvec take the tiles)
-      I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                                      g.ctile ? nullptr : out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
+      if (g.ctile && MODE == RP_F) {
+        I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_, false>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
+                                                        out0, nullptr, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
+      } else {
+        I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
+                                                        out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
+      }
       return;
     }
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
