@@ -53,6 +53,8 @@ struct Chains {
   Rec cur, trj;
   double *p, *p0, *Hcur, *Hprop, *tau;
   int *steps_left, *phase, *status, *nsteps_last;
+  int* cstale;  // 1: the chain's c tiles (ctile) are not those of trj.w - set when a proposal is rejected (trj falls back to cur), cleared by
+                // the row pass of the next evaluation; k_mompass<.., 3> recomputes the tiles of a wave that holds such a chain
   long long *iter, *accepted, *steps_done;
   // scratch
   double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv2, *ljl_part, *qpart, *gpart;
@@ -229,7 +231,8 @@ template <int NB, int MODE, int I8S = 0, bool CN = true>
 __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
                                                  double* __restrict__ out2, double* __restrict__ gpart,
-                                                 double* __restrict__ ljl_part, VSlice vs = VSlice{}, d4* __restrict__ ctile = nullptr) {
+                                                 double* __restrict__ ljl_part, VSlice vs = VSlice{}, d4* __restrict__ ctile = nullptr,
+                                                 int* __restrict__ cstale = nullptr) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
   constexpr bool I8 = I8S > 0;
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
     }
   }
   if (I8 && MODE != RP_G && bad && live) atomicOr(&vs.vbad[cj], 1);
+  if (MODE == RP_F && ctile && cstale && live && rr == 0 && split == 0) cstale[cj] = 0;  // (the chain's c tiles are those of this w now)
   if (MODE != RP_V) {
     lj = col4_sum(lj);
     if (live && rr == 0) ljl_part[(size_t)cj * nsplit + split] = lj;
@@ -598,8 +602,8 @@ __global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, 
 //   CM 2  c loaded: no F product, no exp                             (the other K-1 iterations - same w -, and the pass of the point
 //         evaluation rmhmc.py:158-161, whose row pass k_rowpass<RP_F> has just stored c for the same w in the same layout)
 template <int NB, int CM>
-__global__ __launch_bounds__(256, 2) void k_mompass(DevData dd, int n_chains, int nsplit, const double* __restrict__ wq,
-                                                 const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile) {
+__device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, int nsplit, const double* __restrict__ wq,
+                                             const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile) {
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
   const int lane = threadIdx.x & 63;
@@ -726,6 +730,24 @@ __global__ __launch_bounds__(256, 2) void k_mompass(DevData dd, int n_chains, in
         const int d = NB * (rr + 4 * r) + I;
         if (d < dd.D) out[d] = Q[I][r];
       }
+  }
+}
+//   CM 3  per wavefront: CM 2 when the c tiles of all its 16 chains are those of w (Chains::cstale), CM 1 otherwise.  The first momentum
+//         iteration of a step: the evaluation that ended the previous step left the tiles of w behind for every chain that did not
+//         just reject a proposal (both routes produce the same bits: same operands, same operation order).
+template <int NB, int CM>
+__global__ __launch_bounds__(256, 2) void k_mompass(DevData dd, int n_chains, int nsplit, const double* __restrict__ wq,
+                                                 const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile,
+                                                 const int* __restrict__ cstale = nullptr) {
+  if constexpr (CM == 3) {
+    const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (c0 >= n_chains) return;
+    const int c = c0 + (threadIdx.x & 15);
+    const bool stale = __builtin_amdgcn_ballot_w64(c < n_chains && cstale[min(c, n_chains - 1)] != 0) != 0ull;
+    if (stale) mompass_body<NB, 1>(dd, n_chains, nsplit, wq, uq, qpart, ctile);
+    else mompass_body<NB, 2>(dd, n_chains, nsplit, wq, uq, qpart, ctile);
+  } else {
+    mompass_body<NB, CM>(dd, n_chains, nsplit, wq, uq, qpart, ctile);
   }
 }
 
@@ -1417,6 +1439,7 @@ __device__ __forceinline__ void iter_end_dev(int D, int DP, const Chains& ch, co
   if (lane == 0) {
     ch.Hprop[c] = Hp;
     if (accept) ch.accepted[c] += 1;
+    else if (ch.cstale) ch.cstale[c] = 1;
     ch.iter[c] = it + 1;
     ch.phase[c] = 0;
     if (it + 1 == ip.iter_limit && ip.done_count) atomicAdd(ip.done_count, 1);

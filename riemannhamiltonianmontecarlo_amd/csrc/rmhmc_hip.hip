@@ -84,6 +84,7 @@ struct rmhmc_ctx {
   size_t fused_lds = 0;
   bool medium = false;       // one-launch leapfrog step for small batches with 8 < D <= 32 (medium_step.hip.h)
   size_t medium_lds = 0;
+  bool cdyn = true;          // first momentum pass of a step re-uses the c tiles of chains that did not just reject (RMHMC_CDYN=0: always recomputes)
   bool ccache = true;        // c = v(1-2p) kept per position in the momentum pass's tile layout (RMHMC_CCACHE=0: recomputed every pass)
   bool hmc_traj = false;     // plain HMC in small batches: one launch per trajectory (k_hmc_traj)
   // int8 metric path (metric_i8.hip.h)
@@ -234,15 +235,15 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
       // (with c tiles nobody reads a natural-layout c on this path: k_mompass and k_trvec take the tiles)
       if (g.ctile && MODE == RP_F) {
         I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_, false>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
-                                                        out0, nullptr, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
+                                                        out0, nullptr, g.ch.gpart, g.ch.ljl_part, vs, g.ctile, g.ch.cstale)));
       } else {
         I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                                        out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile)));
+                                                        out2, g.ch.gpart, g.ch.ljl_part, vs, g.ctile, g.ch.cstale)));
       }
       return;
     }
     NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w, out0,
-                                      out2, g.ch.gpart, g.ch.ljl_part, VSlice{}, g.ctile));
+                                      out2, g.ch.gpart, g.ch.ljl_part, VSlice{}, g.ctile, g.ch.cstale));
   });
 }
 
@@ -368,7 +369,10 @@ void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w, int cmode) {
     }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
     switch (cmode) {
-      case 1: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 1>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
+      case 1:  // first pass of a step at this w: the tiles are at hand unless the chain has just rejected a proposal (k_mompass<.., 3>)
+        if (ctx->cdyn) { NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 3>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile, g.ch.cstale)); }
+        else { NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 1>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); }
+        break;
       case 2: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 2>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
       default: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 0>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
     }
@@ -734,7 +738,7 @@ Chains chains_view(const rmhmc_ctx* ctx, long long off, int n) {
     r->ljl += off; r->hld += off;
   }
   v.p = vec(v.p); v.p0 = vec(v.p0); v.Hcur += off; v.Hprop += off; v.tau += off;
-  v.steps_left += off; v.phase += off; v.status += off; v.nsteps_last += off;
+  v.steps_left += off; v.phase += off; v.status += off; v.nsteps_last += off; v.cstale += off;
   v.iter += off; v.accepted += off; v.steps_done += off;
   v.wq = vec(v.wq); v.uq = vec(v.uq); v.PM = vec(v.PM); v.u0 = vec(v.u0); v.q = vec(v.q); v.last = vec(v.last);
   v.Gq = mat(v.Gq); v.rv0 += off * Mp; v.rv2 += off * Mp;
@@ -781,6 +785,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   }
   ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
   if (const char* e = getenv("RMHMC_CCACHE")) ctx->ccache = atoi(e) != 0;
+  if (const char* e = getenv("RMHMC_CDYN")) ctx->cdyn = atoi(e) != 0;
   if (const char* e = getenv("RMHMC_I8_TAIL")) ctx->i8_tail = atoi(e) ? 1 : 0;
   if (flags & RMHMC_FLAG_INT8_INNER_FULL) ctx->i8_inner_drop = 0;
   if (const char* e = getenv("RMHMC_I8_INNER_DROP")) ctx->i8_inner_drop = atoi(e) ? 1 : 0;
@@ -800,7 +805,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       RC(dalloc(ctx, &r->ljl, n)); RC(dalloc(ctx, &r->hld, n));
     }
     RC(dalloc(ctx, &ch.p, n * DP)); RC(dalloc(ctx, &ch.p0, n * DP)); RC(dalloc(ctx, &ch.Hcur, n)); RC(dalloc(ctx, &ch.Hprop, n));
-    RC(dalloc(ctx, &ch.tau, n)); RC(dalloc(ctx, &ch.steps_left, n)); RC(dalloc(ctx, &ch.phase, n)); RC(dalloc(ctx, &ch.status, n));
+    RC(dalloc(ctx, &ch.tau, n)); RC(dalloc(ctx, &ch.steps_left, n)); RC(dalloc(ctx, &ch.phase, n)); RC(dalloc(ctx, &ch.status, n)); RC(dalloc(ctx, &ch.cstale, n));
     RC(dalloc(ctx, &ch.nsteps_last, n)); RC(dalloc(ctx, &ch.iter, n)); RC(dalloc(ctx, &ch.accepted, n)); RC(dalloc(ctx, &ch.steps_done, n));
     RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
     RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
@@ -945,6 +950,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
       // (the fp64 leverage pass of the large-D path; with the int8 path it is allocated only if the certificate sends set_data back to fp64)
       if (!(flags & RMHMC_FLAG_INT8_METRIC)) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * n * Mp));
     }
+    fill_int(ctx, ch.cstale, 1, n);  // (no c tiles yet; the first evaluation clears it)
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
     RC(dalloc(ctx, &ctx->d_miniter, 1));
     RC(dalloc(ctx, &ctx->d_orig, n)); RC(dalloc(ctx, &ctx->d_T, 2 * n));

@@ -637,6 +637,29 @@ def test_c_cache_and_graph_replay_do_not_change_results(hip, monkeypatch):
 
 
 @pytest.mark.parametrize("flags", [0, _capi.int8_metric_flags(6)])
+def test_first_momentum_pass_reuses_c_tiles_bit_identically(hip, monkeypatch, flags):
+    """The first momentum pass of a step takes c from the tiles the previous evaluation left behind, per wavefront, unless one of its chains
+    has just rejected a proposal (k_mompass<.., 3>, Chains::cstale); RMHMC_CDYN=0 recomputes c in that pass for everybody.  Same bits either
+    way, with rejections in the run (step size 0.9: acceptance well below 1)."""
+    M, D, n = 700, 40, 300
+    XX, t = synthetic_logreg(M, D, 11)
+
+    def run(cdyn):
+        monkeypatch.setenv("RMHMC_CDYN", cdyn)
+        with hip.context(M, D, n, flags=flags) as ctx:
+            ctx.set_data(XX, t)
+            ctx.chains_init(seed=8, L=4, eps=0.9, K=4)
+            ctx.chains_run(40)
+            return ctx.chains_state()
+
+    a, b = run("1"), run("0")
+    iters, acc = a[1], a[2]
+    assert (acc < iters).any() and acc.sum() > 0          # some proposals rejected, some accepted
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("flags", [0, _capi.int8_metric_flags(6)])
 def test_log_joint_terms_saturate_like_the_reference(hip, oracle, flags):
     """k_rowpass<RP_F> derives log(1 + e^f) and e^f / (1 + e^f) from p (softplus_sigmoid): where e^f overflows the reference gets
     log(inf) = inf and inf / inf = NaN, where e^-f overflows it gets the finite limits; so must the kernel, value for value."""
