@@ -231,7 +231,17 @@ def main():
         # post-burn-in phase (TimeTaken semantics, rmhmc.py:194-198).  ESS by tools.CalculateESS semantics with
         # the MATLAB FFT length (no wrap-around); estimated on a subset of chains to bound the host FFT work.
         burn = 100
+        # Under rocprofv3 the sampler's phase schedule (graph replays of the whole batch followed by direct launches of its prefixes)
+        # makes librocprofiler-sdk 7.2 fault in its dispatch-completion callback once the step holds the two-wave tail tiles (backtrace:
+        # hsa-runtime async handler -> librocprofiler-sdk.so; any one of RMHMC_GRAPH=0 / RMHMC_SORTED=0 / RMHMC_I8_TAIL=0 avoids it,
+        # and nothing happens without the profiler).  A profiled run therefore takes this leg without graph replay.
+        profiled = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        graph_off = profiled and "RMHMC_GRAPH" not in os.environ
+        if graph_off:
+            os.environ["RMHMC_GRAPH"] = "0"
         st = ctx.sample_stats_dev(torch.device("cuda", dev), burn + args.ess_iters, burn, L=L, eps=eps, K=K, seed=7, chain_offset=rank * n)
+        if graph_off:
+            del os.environ["RMHMC_GRAPH"]
         me = torch.nan_to_num(st["ess"], nan=float("inf")).amin(dim=1)        # per chain: min over dimensions
         me = me[torch.isfinite(me)]
         tot = float(me.sum()); secs = st["seconds"]; lsteps = float(st["leapfrog_steps"].sum()); acc_n = float(st["accepted"].sum())
@@ -243,7 +253,7 @@ def main():
                "post_burn_in_transitions": args.ess_iters, "burn_in": burn, "compat": bool(args.compat),
                "mean_min_ess_per_chain": tot / (n * world), "chains": n * world,
                "leapfrog_steps_per_sec_during_sampling": lsteps / secs,
-               "acceptance": acc_n / float((burn + args.ess_iters) * n * world),
+               "acceptance": acc_n / float((burn + args.ess_iters) * n * world), "graph_replay": not graph_off,
                "note": "per-chain ESS (MATLAB CalculateStatistics.m semantics: ESS per chain, min over dimensions; tools.py:32-74 "
                        "estimator with linear autocovariances = the MATLAB FFT length, no wrap-around), summed over all chains; seconds = "
                        "the post-burn-in window of rmhmc.py:194-198; computed on the device by rmhmc_sample_stats_dev (no sample transfer)"}
