@@ -588,9 +588,9 @@ __global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, 
 // K3b  fused quadratic-term pass on the matrix cores, 16 chains per wavefront:
 //        q_c[d] = sum_n c_n(w_c) (x_n.u_c)^2 x_nd  = u' dG/dw_d u      (rmhmc.py:104-107,158-161)
 // as three small GEMMs per 16 data rows:  F = X W, S = X U  (16 rows x 16 chains, K = D) and
-// Q += X' R with R = c(F) S^2.  The accumulator layout of F/S (register r <-> data row 4(lane>>4)+r,
-// column lane&15 = chain) is exactly the B-operand layout of the third product for the 4-row chunk r,
-// so R feeds the matrix core without any lane movement.  X is read once per 16 chains.
+// Q += X' R with R = c(F) S^2.  The accumulator layout of F/S (tile A: register r <-> data row n0 + 8(lane>>4) + 2r,
+// tile B: the next row; column lane&15 = chain) is exactly the B-operand layout of the third product for the
+// row quadruple r of that tile, so R feeds the matrix core without any lane movement.  X is read once per 16 chains.
 // Rows are split over blockIdx.y; partial sums go to qpart[split][chain][d] (summed, in fixed order,
 // by the momentum-update kernel: deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, 
 // as much again as the pass's 48 MFMAs per tile), so c is computed once per position and kept in the accumulator layout of this
 // kernel ("tile native": ctile[(chain group * nb16 + row block) * 64 + lane] = the lane's four values, 2 KB contiguous per tile):
 //   CM 0  c from F = X W as above
-//   CM 1  the same, and the tile's values are stored                (first momentum fixed-point iteration of a step, rmhmc.py:102-110)
+//   CM 1  the same, and the tile's values are stored                (first momentum fixed-point iteration of a step, rmhmc.py:102-110,
+//         for the wavefronts of k_mompass<.., 3> that hold a chain whose tiles are stale)
 //   CM 2  c loaded: no F product, no exp                             (the other K-1 iterations - same w -, and the pass of the point
 //         evaluation rmhmc.py:158-161, whose row pass k_rowpass<RP_F> has just stored c for the same w in the same layout)
 template <int NB, int CM>
