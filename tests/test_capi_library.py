@@ -93,6 +93,9 @@ def test_int8_metric_flag_helpers():
     hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "rmhmc.h")).read()
     assert re.search(r"#define RMHMC_FLAG_INT8_METRIC \(1u << 5\)", hdr)
     assert re.search(r"#define RMHMC_FLAG_INT8_SLICES\(S\) \(\(\(uint32_t\)\(S\) & 7u\) << 12\)", hdr)
+    # every single-bit flag of the header has the same value in the binding
+    for name, bit in re.findall(r"#define RMHMC_(FLAG_[A-Z0-9_]+) \(1u << (\d+)\)", hdr):
+        assert getattr(_capi, name) == 1 << int(bit), name
 
 
 def test_build_tracks_every_included_header():
