@@ -1060,38 +1060,69 @@ __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int 
 }
 
 // Lower triangle of (L L')^-1 in place of the Cholesky factor L held in the LDS image A (one wavefront, lane = row; rdiag as
-// produced by chol_lds_blk).  W = L^-1 in place, column by column from the right: W[i][j] = -(sum_{m>j} W[i][m] L[m][j]) / L[j][j]
-// reads only columns > j of W and column j of L, which is overwritten afterwards; then G^-1 = W' W on the fp64 matrix cores with
+// produced by chol_lds_blk).  W = L^-1 in place by 16 x 16 blocks (see below); then G^-1 = W' W on the fp64 matrix cores with
 // the operands read straight from the LDS image (A[i][k] = W[m0+k][16I+i], B[k][j] = W[m0+k][16J+j]: one ds_read per 16-column
 // tile serves both), lower tiles only, written back into A.
 template <int NB, bool PK = false>
 __device__ __forceinline__ void spd_inverse_lds(double* A, int D, int lane, double rdiag) {
   constexpr int DPc = 16 * NB;
-  // W = L^-1 in place.  Diagonal and the zero upper triangle / padding rows first, so that every lane runs the same loop.
+  // W = L^-1 in place, by 16 x 16 blocks.  (A column sweep over the whole matrix - 63 dependent steps with dot products of up to 63
+  // terms - was 590 of the 890 us of k_factor_full.)
+  //   1. diagonal blocks W_II = L_II^-1, all NB of them in the same 15 column steps (lane = row, each lane in its own block);
+  //   2. block column by block column, W_IJ = -W_II (sum_{K=J}^{I-1} L_IK W_KJ) on the fp64 matrix cores, operands straight from
+  //      the LDS image; the inner sum stays in the accumulator layout, which is the B-operand layout of the product with W_II.
+  // Block (I, J) of L is read for the last time when W_IJ is computed, and is overwritten by it.
   {
-    double* rowp = A + rm_row<PK>(lane);
-    const int rlen = min(DPc, rm_len<PK>(lane));
-    if (lane < D) {
-      rowp[lane] = rdiag;
-      for (int m = lane + 1; m < rlen; ++m) rowp[m] = 0.0;
-    } else {
-      for (int m = 0; m < rlen; ++m) rowp[m] = 0.0;
+    const bool act = lane < DPc;            // (NB < 4: the lanes beyond the matrix read a valid row and never write)
+    const int row = act ? lane : DPc - 1;
+    double* rowp = A + rm_row<PK>(row);
+    const int rlen = min(DPc, rm_len<PK>(row));
+    const int il = row & 15, cb0 = row & ~15;  // position inside / first row and column of the lane's diagonal block
+    // diagonal 1 / L_ii and the zero upper triangle (rows / columns >= D are the identity padding of
+    // chol_lds_blk: they invert to themselves and are zeroed at the end)
+    if (act) {
+      rowp[row] = rdiag;
+      for (int m = row + 1; m < rlen; ++m) rowp[m] = 0.0;  // (packed image: the row ends with its diagonal block)
     }
     __builtin_amdgcn_wave_barrier();
-    const int mEnd = PK ? min(D, rlen) : D;  // (PK: W[lane][m] = 0 beyond the row's own blocks, which are not stored)
-    for (int j = D - 2; j >= 0; --j) {
+    for (int jl = 14; jl >= 0; --jl) {
+      // W[i][j] = -(sum_{m > j} W[i][m] L[m][j]) / L[j][j] inside the diagonal block (W[i][m] = 0 for m > i), j = cb0 + jl
       double s0 = 0.0, s1 = 0.0;
-      int m = j + 1;
-      if ((m & 1) && m < mEnd) { s0 = fma(rowp[m], A[rm_row<PK>(m) + j], s0); ++m; }
-      for (; m + 4 <= mEnd; m += 4) {
-        const double2 w01 = lds2(rowp + m), w23 = lds2(rowp + m + 2);
-        s0 = fma(w01.x, A[rm_row<PK>(m) + j], s0); s1 = fma(w01.y, A[rm_row<PK>(m + 1) + j], s1);
-        s0 = fma(w23.x, A[rm_row<PK>(m + 2) + j], s0); s1 = fma(w23.y, A[rm_row<PK>(m + 3) + j], s1);
+#pragma unroll
+      for (int ml = 1; ml < 16; ++ml) {
+        const double t = (ml > jl) ? rowp[cb0 + ml] * A[rm_row<PK>(cb0 + ml) + cb0 + jl] : 0.0;
+        if (ml & 1) s0 += t; else s1 += t;
       }
-      for (; m < mEnd; ++m) s0 = fma(rowp[m], A[rm_row<PK>(m) + j], s0);
-      const double rj = rdlane(rdiag, j);
+      const double rj = A[rm_row<PK>(cb0 + jl) + cb0 + jl];  // W[j][j] = 1 / L[j][j], set above
       __builtin_amdgcn_wave_barrier();
-      if (lane > j && lane < D) rowp[j] = -(s0 + s1) * rj;
+      if (act && il > jl) rowp[cb0 + jl] = -(s0 + s1) * rj;
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int kk = lane >> 4, ii = lane & 15;
+#pragma unroll
+    for (int J = 0; J + 1 < NB; ++J) {
+#pragma unroll
+      for (int I = J + 1; I < NB; ++I) {
+        d4 T = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int K = J; K < I; ++K)
+#pragma unroll
+          for (int k0 = 0; k0 < 16; k0 += 4)
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(A[rm_row<PK>(16 * I + ii) + 16 * K + k0 + kk], A[rm_row<PK>(16 * K + k0 + kk) + 16 * J + ii], T, 0, 0,
+                                                     0);
+        d4 R = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R = __builtin_amdgcn_mfma_f64_16x16x4f64(A[rm_row<PK>(16 * I + ii) + 16 * I + 4 * r + kk], T[r], R, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[rm_row<PK>(16 * I + kk + 4 * r) + 16 * J + ii] = -R[r];
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // rows of the padding: W = 0 there, so that G^-1 = W' W is zero outside D x D
+    if (D < DPc) {
+      if (lane >= D && lane < DPc)
+        for (int m = 0; m < rlen; ++m) rowp[m] = 0.0;
       __builtin_amdgcn_wave_barrier();
     }
   }
