@@ -904,15 +904,30 @@ __device__ __forceinline__ int chol_lds_blk(double* A, int D, int lane, double& 
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
     const int c0 = 16 * kb;
-    for (int j = 0; j < 16; ++j) {
-      const int jj = c0 + j;
-      const double s = neg_dot_lds(rowp + c0, A + rm_row<PK>(jj) + c0, j, rowp[jj]);  // meaningful for lanes jj..DPc-1
-      const double sjj = rdlane(s, jj);
-      if (!(sjj > 0.0)) bad = 1;
-      const double rinv = rsqrt(sjj);
+    {
+      // The 16-column panel in REGISTERS (lane = row, a[j] = column c0 + j), right-looking: the pivot and the multipliers of a column
+      // are v_readlane broadcasts (the indices are compile-time constants), so the 16 dependent column steps touch no LDS and need no
+      // barrier (in LDS, left-looking, a step cost ~700 cycles of round trips: 145 us of k_factor_full / k_factor_solve each).
+      // Lanes above the panel (rows < c0) and beyond the matrix carry values that are never stored.
+      const double* rp = A + rm_row<PK>(min(max(lane, c0), DPc - 1)) + c0;
+      double a[16];
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) { const double2 t = lds2(rp + j); a[j] = t.x; a[j + 1] = t.y; }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int jj = c0 + j;
+        const double sjj = rdlane(a[j], jj);
+        if (!(sjj > 0.0)) bad = 1;
+        const double rinv = rsqrt(sjj);
+        a[j] = (lane == jj) ? sjj * rinv : a[j] * rinv;
+        if (lane == jj) rdiag = rinv;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], rdlane(a[j], c0 + k), a[k]);
+      }
       __builtin_amdgcn_wave_barrier();
-      if (lane == jj) { rowp[jj] = sjj * rinv; rdiag = rinv; }
-      else if (lane > jj && lane < DPc) rowp[jj] = s * rinv;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (lane >= c0 + j && lane < DPc) rowp[c0 + j] = a[j];
       __builtin_amdgcn_wave_barrier();
     }
     if (kb + 1 < NB) {
