@@ -1380,8 +1380,10 @@ __device__ __forceinline__ void iter_begin_dev(int D, int DP, const Chains& ch, 
   if (ch.phase[c] != 0) return;
   const long long it = ch.iter[c];
   if (it >= ip.iter_limit) return;
-  // trajectory starts from the cached record of the current point (wNew = w.copy(), rmhmc.py:47)
-  copy_rec(ch.trj, ch.cur, c, D, DP, lane);
+  // trajectory starts from the cached record of the current point (wNew = w.copy(), rmhmc.py:47).  After an ACCEPTED proposal the two
+  // records are already identical (k_iter_end has just copied trj to cur), so the 2 x 64 KB copy is only made after a rejection - the
+  // same per-chain flag that tells k_mompass the c tiles are not those of trj.w - and on paths that do not keep the flag (it stays 1).
+  if (!ch.cstale || ch.cstale[c]) copy_rec(ch.trj, ch.cur, c, D, DP, lane);
   const long long oc = ip.orig ? ip.orig[c] : c;
   // draws: z ~ randn(1,D), u_len ~ rand(), g_dir ~ randn()   (rmhmc.py:80,89,90)
   draw_normals(ip, c, it, D, lane, zs, oc);
