@@ -997,11 +997,20 @@ __device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane
   return b;
 }
 
-// DxD matrix (row stride DP in HBM) -> LDS, eight row loads in flight
+// DxD matrix (row stride DP in HBM) -> LDS, sixteen row loads in flight (the kernels that start with it are one wavefront per chain
+// and wait for this load before anything else: 8 KB in flight per wavefront instead of 4)
 template <bool PK = false>
 __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict__ G, int D, int DP, int lane) {
   const int l = lane < D ? lane : 0;
   int i = 0;
+  for (; i + 16 <= D; i += 16) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = G[(i + q) * DP + l];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (lane < rm_len<PK>(i + q)) A[rm_row<PK>(i + q) + lane] = v[q];
+  }
   for (; i + 8 <= D; i += 8) {
     double v[8];
 #pragma unroll
