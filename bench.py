@@ -129,6 +129,10 @@ def main():
     ap.add_argument("--ess-iters", type=int, default=-1,
                     help="run RMHMC for this many post-burn-in transitions (+100 burn-in) per chain and report min-ESS/sec, the second half of "
                          "the metric; -1 (default): 200 (c1-c3; config 5 at 1 s per global step: 0 = off), 0: off")
+    ap.add_argument("--burn-in-steps", type=int, default=-1,
+                    help="untimed global leapfrog steps between chains_init and the warmup, so that the timed steps run on chains at "
+                         "stationarity (the metric's window is the post-burn-in sampling phase, rmhmc.py:194-198).  Default: 300 for the "
+                         "large batched workloads (about 85 transitions), 0 otherwise; alternates.cold_start times the first steps from theta0")
     ap.add_argument("--no-fp64-roofline", action="store_true", help="skip the extra fp64-matrix-core run behind roofline_fp64")
     args = ap.parse_args()
 
@@ -176,6 +180,10 @@ def main():
     if args.i8_slices and not i8_active:   # not certified to 1e-9: the library runs this data on the fp64 matrix cores
         args.i8_slices = 0
     ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
+    if args.burn_in_steps < 0:
+        args.burn_in_steps = 300 if (8 < D <= 64 and n * float(M) * D * D >= 1e9) else 0
+    if args.burn_in_steps:
+        ctx.chains_run(args.burn_in_steps)   # untimed: from theta0 = 1e-3 (rmhmc.py:27) to stationarity
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,7 +204,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    KT_NAMES = ("assemble", "assemble_i8", "assemble_i8_inner", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small",
+    KT_NAMES = ("assemble", "assemble_i8", "assemble_i8_inner", "assemble_i8_delta", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small",
                 "fused", "medium", "total")
     # un-timed repetition of the same K steps with HIP events around every launch (on the library's own stream)
     ctx.kernel_time("enable"); ctx.kernel_time("reset")
@@ -311,6 +319,11 @@ def main():
                                                 "avg_launch_ms": kt["assemble_i8_inner"][0] / kt["assemble_i8_inner"][1] * 1e3,
                                                 "frac": 2.0 * n * M * NP * ((S - 1) * S // 2) / (kt["assemble_i8_inner"][0] / kt["assemble_i8_inner"][1]) / INT8_MFMA_PEAK}
                                                if kt["assemble_i8_inner"][1] else None),
+                    # the assembly of the evaluation that ends a step: G(last iterate) + the GEMM of the v differences, from as many
+                    # slices as the largest difference needs (4 at stationarity: 10 slice products; 5 / 6 in the first steps from theta0)
+                    "delta_assembly": ({"launches": kt["assemble_i8_delta"][1],
+                                        "avg_launch_ms": kt["assemble_i8_delta"][0] / kt["assemble_i8_delta"][1] * 1e3}
+                                       if kt["assemble_i8_delta"][1] else None),
                     "survey8d_streaming_model_frac_NOT_A_BOUND": (value / world) * bytes_step / HBM_PEAK,
                     "step_fp64_frac": (value / world) * flops_step / FP64_MFMA_PEAK,
                     "note": "survey8d_streaming_model_frac = steps/s x 80 M D bytes / 8 TB/s, the figure SURVEY 8(d) / north_star ask for; it can "
@@ -355,12 +368,17 @@ def main():
             "dtype_detail": ("f64 throughout; the two O(M D^2) contractions (metric assembly, leverages) as exact integer GEMMs: operands cut into %d "
                              "signed-byte slices, int8 MFMA with int32 accumulation, combined in f64 (G to ~2e-14 of the f64 oracle at 6 slices)%s"
                              % (args.i8_slices, "; the metric of the position fixed-point iterates before the last (it only steers the next iterate) "
-                                "from the 5 most significant slices (effect on theta after a step < 1e-11)" if args.i8_slices == 6 else ""))
+                                "from the 5 most significant slices (effect on theta after a step < 1e-11); the metric at the end of a step as G(last iterate) + the "
+                                "exact integer GEMM of the v differences (4-6 slices as their size needs, identical grids)" if args.i8_slices == 6 else ""))
                             if args.i8_slices else "f64 throughout (fp64 matrix cores)",
             "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
                        "D": D, "M": M, "leapfrog_L": L, "step_size": eps, "fixed_point_K": K,
-                       "compat": bool(args.compat), "metric_assembly": (("int8 x %d slices" % args.i8_slices) + (" (position fixed-point iterates before the last: 5; "
+                       "compat": bool(args.compat),
+                       "chain_state": ("stationary: %d untimed global steps from theta0 before the warmup (the metric's window is the post-burn-in "
+                                       "sampling phase, rmhmc.py:194-198); alternates.cold_start = the first steps from theta0" % args.burn_in_steps)
+                       if args.burn_in_steps else "first steps from theta0 = 1e-3 (rmhmc.py:27)",
+                       "metric_assembly": (("int8 x %d slices" % args.i8_slices) + (" (position fixed-point iterates before the last: 5; "
                                            "RMHMC_FLAG_INT8_INNER_FULL = 6 everywhere, see alternates.int8_x6_inner_full)" if args.i8_slices == 6 else ""))
                        if args.i8_slices else "fp64",
                        "int8_error_certificate": i8_bound if i8_bound > 0 else None, "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
@@ -381,10 +399,13 @@ def main():
     if rank == 0:
         big = 8 < D <= 256 and n * float(M) * D * D >= 1e9
 
-        def run_variant(sl, steps, timing, extra=0):
+        def run_variant(sl, steps, timing, extra=0, burn=None):
             c2 = lib.context(M, D, n, flags=flags | extra | (_capi.int8_metric_flags(sl) if sl else 0), device=dev)
             c2.set_data(XX, t)
             c2.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
+            burn = args.burn_in_steps if burn is None else burn
+            if burn:
+                c2.chains_run(burn)
             c2.chains_run(min(args.warmup, 2) or 1)
             torch.cuda.synchronize(); ta = time.perf_counter()
             c2.chains_run(steps)
@@ -422,6 +443,8 @@ def main():
                 alts[name], _ = run_variant(sl, 3, False)
             if args.i8_slices == 6:   # all four assemblies of a step from 6 slices
                 alts["int8_x6_inner_full"], _ = run_variant(6, 3, False, _capi.FLAG_INT8_INNER_FULL)
+            if args.burn_in_steps and args.i8_slices:   # the headline's arithmetic on the first steps from theta0 (no burn-in)
+                alts["cold_start"], _ = run_variant(args.i8_slices, args.steps, False, burn=0)
             if "roofline_fp64" in out:
                 alts["fp64_mfma"] = {"value": out["roofline_fp64"]["value"], "ms_per_step": out["roofline_fp64"]["ms_per_step"]}
             out["alternates"] = alts

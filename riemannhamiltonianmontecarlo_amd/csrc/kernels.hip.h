@@ -179,6 +179,43 @@ __device__ __forceinline__ void slice_digits(const d4& vv, double vscale, double
   }
 }
 
+// The two halves of the fast path of slice_digits (S = 6) on their own, for the delta slices of k_rowpass<.., DELTA>:
+// digits of z = 2^52 + B + N (four values) and back.  Qf[j] byte r = mantissa byte j of z_r, xor 0x80.
+__device__ __forceinline__ void z_to_digits6(const double (&z)[4], unsigned (&Qf)[6]) {
+  unsigned L[4], H[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { L[r] = (unsigned)__double2loint(z[r]); H[r] = (unsigned)__double2hiint(z[r]); }
+  const unsigned a = __builtin_amdgcn_perm(L[1], L[0], 0x05010400u), b2 = __builtin_amdgcn_perm(L[1], L[0], 0x07030602u);
+  const unsigned c = __builtin_amdgcn_perm(L[3], L[2], 0x05010400u), d2_ = __builtin_amdgcn_perm(L[3], L[2], 0x07030602u);
+  Qf[0] = __builtin_amdgcn_perm(c, a, 0x05040100u) ^ 0x80808080u;
+  Qf[1] = __builtin_amdgcn_perm(c, a, 0x07060302u) ^ 0x80808080u;
+  Qf[2] = __builtin_amdgcn_perm(d2_, b2, 0x05040100u) ^ 0x80808080u;
+  Qf[3] = __builtin_amdgcn_perm(d2_, b2, 0x07060302u) ^ 0x80808080u;
+  const unsigned ah = __builtin_amdgcn_perm(H[1], H[0], 0x05010400u), ch = __builtin_amdgcn_perm(H[3], H[2], 0x05010400u);
+  Qf[4] = __builtin_amdgcn_perm(ch, ah, 0x05040100u) ^ 0x80808080u;
+  Qf[5] = __builtin_amdgcn_perm(ch, ah, 0x07060302u) ^ 0x80808080u;
+}
+// (the 4 x 4 byte transpose is its own inverse; the upper half of the high word is that of 2^52: N + B < 2^48)
+__device__ __forceinline__ void digits6_to_z(const unsigned (&Qd)[6], double (&z)[4]) {
+  unsigned Q[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) Q[j] = Qd[j] ^ 0x80808080u;
+  const unsigned a = __builtin_amdgcn_perm(Q[1], Q[0], 0x05010400u), b2 = __builtin_amdgcn_perm(Q[1], Q[0], 0x07030602u);
+  const unsigned c = __builtin_amdgcn_perm(Q[3], Q[2], 0x05010400u), d2_ = __builtin_amdgcn_perm(Q[3], Q[2], 0x07030602u);
+  unsigned L[4], H[4];
+  L[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+  L[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+  L[2] = __builtin_amdgcn_perm(d2_, b2, 0x05040100u);
+  L[3] = __builtin_amdgcn_perm(d2_, b2, 0x07060302u);
+  const unsigned ah = __builtin_amdgcn_perm(Q[5], Q[4], 0x05010400u), bh = __builtin_amdgcn_perm(Q[5], Q[4], 0x07030602u);
+  H[0] = __builtin_amdgcn_perm(0x43300000u, ah, 0x07060100u);
+  H[1] = __builtin_amdgcn_perm(0x43300000u, ah, 0x07060302u);
+  H[2] = __builtin_amdgcn_perm(0x43300000u, bh, 0x07060100u);
+  H[3] = __builtin_amdgcn_perm(0x43300000u, bh, 0x07060302u);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) z[r] = __hiloint2double((int)H[r], (int)L[r]);
+}
+
 // log(1 + e^f) and e^f / (1 + e^f) of the log joint and its gradient (rmhmc.py:100,140,167-168) from p = 1 / (1 + e^-f), which the row
 // pass has at hand, instead of a second exp, an ocml log and a second divide (148 -> 77 fp64 instructions per data row in k_rowpass<RP_F>,
 // whose time is the fp64 VALU's):  e^f / (1 + e^f) = p,  log(1 + e^f) = max(f, 0) - log(y) with y = p (f >= 0) or 1 - p (f < 0), y in
@@ -223,11 +260,19 @@ struct VSlice {
   // v 2^vexp with vexp = floor(f_lo log2 e) - 3 (>= 0) still fits the grid; the assembly's epilogue divides by 2^vexp.
   int* vexp;
   const double *cmin, *cmax;
+  // k_rowpass<.., DELTA> (the evaluation at the end of a leapfrog step): the planes hold N_old = rint(v_old 2^(8S + vexp)) of the last
+  // position iterate, whose G is still in Gq.  The pass leaves the slices of N_new - N_old in their place, the chain's exponent in
+  // vexp_d (vexp itself is only read) and max |N_new - N_old| over the group in dmax; a chain whose exponent has changed is marked in
+  // rebase and gets the slices of N_new itself (its G is overwritten, not added to).  See launch_assemble_i8_delta.
+  int* vexp_d = nullptr;
+  int* rebase = nullptr;
+  unsigned long long* dmax = nullptr;
+  int force_rebase = 0;  // (tests)
 };
 // I8S: 0 = fp64 row vectors, else the number of byte slices (compile time: the slicing code is straight-line)
 // (the slicing RP_F variant takes 190 VGPRs = 2 waves per SIMD; asked for 3 / 4 waves it spills: rowpass 2.51 -> 2.99 / 3.57 ms per step)
 // CN: RP_F writes c in natural layout to out2 (off on the int8 path when c tiles are kept: its consumers take the tiles)
-template <int NB, int MODE, int I8S = 0, bool CN = true>
+template <int NB, int MODE, int I8S = 0, bool CN = true, bool DELTA = false>
 __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, int nsplit, const int* __restrict__ phase,
                                                  const double* __restrict__ wq, double* __restrict__ out0,
                                                  double* __restrict__ out2, double* __restrict__ gpart,
@@ -260,8 +305,15 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
     m1 = fmax(m1, __shfl_xor(m1, 32, 64));
     const double flo = m1 - s1;
     if (flo > 4.0 && flo < 1e300) vsh = (int)fmin(900.0, floor(flo * 1.4426950408889634) - 3.0);
-    if (live && rr == 0 && split == 0) vs.vexp[cj] = vsh;
+    if constexpr (DELTA) {
+      if (live && rr == 0 && split == 0) { vs.vexp_d[cj] = vsh; vs.rebase[cj] = (vsh != vs.vexp[cj] || vs.force_rebase) ? 1 : 0; }
+    } else {
+      if (live && rr == 0 && split == 0) vs.vexp[cj] = vsh;
+    }
   }
+  bool rebase = false;
+  double dmx = 0.0;  // DELTA: max |N_new - N_old| of the lane
+  if constexpr (DELTA) rebase = vsh != vs.vexp[cj] || vs.force_rebase;
   double vscale = 1.0, vmagic = 4503599627370496.0;  // 2^(8S + vexp) and 2^52 + B (fast slicing, S <= 6)
   if (I8 && MODE != RP_G) {
     vscale = ldexp(1.0, 8 * I8S + vsh);
@@ -398,8 +450,49 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
       // QA[j] / QB[j]: byte r = digit j (least significant first) of rint(v 2^(8S + vexp)) for the tile's element r; interleaved
       // they are the 8 bytes of slice plane S-1-j for rows nl .. nl+7.  Only live chains and stages inside the planes are stored.
       unsigned QA[I8S], QB[I8S];
-      slice_digits<I8S>(vA, vscale, vmagic, vsh, bad, QA);
-      slice_digits<I8S>(vB, vscale, vmagic, vsh, bad, QB);
+      if constexpr (DELTA) {
+        static_assert(!DELTA || I8S == 6, "delta slices: six planes");
+        // z = 2^52 + B + N for the new values, the same for the stored ones from their digits; the difference is N_new - N_old exactly
+        double zA[4], zB[4], oA[4], oB[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double xa_ = vA[r], xb_ = vB[r];
+          if (!(xa_ >= 0.0 && xa_ <= 0.25)) { bad = 1; xa_ = 0.0; }
+          if (!(xb_ >= 0.0 && xb_ <= 0.25)) { bad = 1; xb_ = 0.0; }
+          zA[r] = fma(xa_, vscale, vmagic);
+          zB[r] = fma(xb_, vscale, vmagic);
+          oA[r] = vmagic;
+          oB[r] = vmagic;
+        }
+        if (live && B < vs.nks && !rebase) {
+          const int8_t* vp = vs.Vs + ((size_t)B * vs.nCp + cj) * 32 + 8 * rr;
+          const size_t plane = (size_t)vs.nks * vs.nCp * 32;
+          unsigned OA[6], OB[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const uint2 q = *(const uint2*)(vp + (size_t)(5 - j) * plane);
+            OA[j] = __builtin_amdgcn_perm(q.y, q.x, 0x06040200u);
+            OB[j] = __builtin_amdgcn_perm(q.y, q.x, 0x07050301u);
+          }
+          digits6_to_z(OA, oA);
+          digits6_to_z(OB, oB);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double da = zA[r] - oA[r], db = zB[r] - oB[r];
+          if (live && B < vs.nks) dmx = fmax(dmx, fmax(fabs(da), fabs(db)));  // (blocks past the planes: padding rows, never stored)
+          zA[r] = da + vmagic;
+          zB[r] = db + vmagic;
+        }
+        unsigned QA6[6], QB6[6];
+        z_to_digits6(zA, QA6);
+        z_to_digits6(zB, QB6);
+#pragma unroll
+        for (int j = 0; j < I8S; ++j) { QA[j] = QA6[j]; QB[j] = QB6[j]; }
+      } else {
+        slice_digits<I8S>(vA, vscale, vmagic, vsh, bad, QA);
+        slice_digits<I8S>(vB, vscale, vmagic, vsh, bad, QB);
+      }
       if (live && B < vs.nks) {
         int8_t* vp = vs.Vs + ((size_t)B * vs.nCp + cj) * 32 + 8 * rr;
         const size_t plane = (size_t)vs.nks * vs.nCp * 32;
@@ -414,6 +507,12 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
     }
   }
   if (I8 && MODE != RP_G && bad && live) atomicOr(&vs.vbad[cj], 1);
+  if constexpr (DELTA) {
+    if (!live) dmx = 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) dmx = fmax(dmx, __shfl_xor(dmx, o, 64));
+    if (lane == 0 && dmx > 0.0) atomicMax(vs.dmax, (unsigned long long)__double_as_longlong(dmx));  // (>= 0: the bit patterns order like the values)
+  }
   if (MODE == RP_F && ctile && cstale && live && rr == 0 && split == 0) cstale[cj] = 0;  // (the chain's c tiles are those of this w now)
   if (MODE != RP_V) {
     lj = col4_sum(lj);

@@ -30,6 +30,10 @@
 //   2^(cexp[a]+cexp[b]), the inverse of the equilibrated metric), because x' G^-1 x is a sum of O(1) terms whose two factors vary by
 //   the SQUARE of the column scales in opposite directions.  Then Q~ carries the CHAIN's exponent and Z~ the DATA ROW's, so h_n is
 //   accurate relative to max|Q~| max_a|x~_na|^2 for every (chain, row): |dh_n| <= S NP 2^(eq_c + ez_n + 4 - 8S), NP = D(D+1)/2.
+//   Delta assembly (I8Delta below; S = 6, the evaluation that ends a leapfrog step): G = G(last position iterate) + the integer GEMM of
+//   the DIFFERENCE of the two v grids.  The grids and their rounding are those of a full assembly (the difference of two grid values is
+//   exact); only the dropped slice products (i + j >= S) enter twice, once with the digits of the base matrix and once with those of
+//   the difference: |dG_ab| <= (2S - 1) M 2^(e_ab-8S), which is what the certificate uses when the delta assembly is on.
 //   Inner iterates: at S = 6 the assemblies whose G only steers a fixed-point iterate (position iterates before the last, launch_assemble in
 //   rmhmc_hip.hip) use the S - 1 most significant slices of the same operands, i.e. the bounds above with S - 1 for THOSE matrices only; every
 //   G that enters a Hamiltonian, a leverage, rmhmc_metric or the last iterate has the full S (RMHMC_FLAG_INT8_INNER_FULL: all of them).
@@ -487,6 +491,24 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
     }
 }
 
+// Delta assembly (the evaluation at the end of a leapfrog step, launch_assemble_i8_delta): the planes hold the digits of
+// N_new - N_old, G(w_old) is in Gq, and G(w_new) = G(w_old) + sum_n (N_new - N_old)_n z_n 2^-(8S + vexp) is summed from as many of the
+// LEAST significant planes as max |N_new - N_old| needs: the instantiations S' = 6, 5, 4 are all launched on the V planes S - S' ..
+// S - 1 (and the Z planes 0 .. S' - 1: the same products i + j < S as the full assembly, minus those with a zero V plane), each
+// reads the maximum the row pass left in *dsel and all but the one whose S' matches return at once.  cscale = 2^-8(S - S').
+struct I8Delta {
+  const unsigned long long* dsel;  // null: ordinary assembly
+  const int* rebase;               // chains whose planes hold N_new itself (the exponent of their grid has changed): G is overwritten
+  double cscale;
+};
+// S' balanced digits hold |N| <= 127 (256^S' - 1) / 255 = 0.498 256^S'
+__device__ __forceinline__ int i8_delta_slices(unsigned long long bits) {
+  const double mx = __longlong_as_double((long long)bits);
+  if (mx <= 0.49 * 4294967296.0) return 4;
+  if (mx <= 0.49 * 1099511627776.0) return 5;
+  return 6;
+}
+
 // the assembly proper: lower triangle of G[c] = C[c][:] * scale + I/alpha, natural row-major DP x DP like k_assemble (the
 // Cholesky kernels never read above the diagonal; rmhmc_metric mirrors it on the host for G_out)
 // (waves per SIMD stated explicitly: with 4 waves per workgroup the compiler otherwise budgets 256 registers and shuttles
@@ -495,7 +517,8 @@ template <int S, int WN, int TN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
                                                           int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
                                                           const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
-                                                          size_t plane_stride, const int* __restrict__ vexp, int npb) {
+                                                          size_t plane_stride, const int* __restrict__ vexp, int npb, I8Delta dl) {
+  if (dl.dsel && i8_delta_slices(*dl.dsel) != S) return;
   int cb, pb;  // npb: pair blocks of this launch (all of them, or the full ones when k_assemble_i8_tail takes the ragged rest)
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, npb, cb, pb)) return;
   // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow.
@@ -517,8 +540,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
     if (i < I8_BM) {
       const int c = cb * I8_BM + i;
       const bool ok = c < n_chains && phase[min(c, n_chains - 1)] == 1;
-      s_coff[i] = ok ? 1 : 0;
-      s_cmul[i] = ok ? (vbad[c] ? __builtin_nan("") : ldexp(1.0, -vexp[c])) : 0.0;
+      s_coff[i] = ok ? ((dl.rebase && dl.rebase[c]) ? 3 : 1) : 0;  // (3: never added to what Gq holds)
+      s_cmul[i] = ok ? (vbad[c] ? __builtin_nan("") : ldexp(dl.cscale, -vexp[c])) : 0.0;
     } else {
       const int j = i - I8_BM, p = pb * BN + j;
       const bool ok = p < pr.NP;
@@ -537,7 +560,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
     // lower triangle only (pairs run along its rows, contiguous in p): all the factor kernels read
     double* gp = Gout + (size_t)min(c, n_chains - 1) * DP * DP + max(off, 0);
     double g = (val * fabs(ps)) * s_cmul[ci];
-    if (accumulate) g += *gp;
+    // accumulate bit 0: a later piece of a long data set; bit 1: delta assembly (all chains but the re-based ones)
+    if ((accumulate & 1) || ((accumulate & 2) && s_coff[ci] != 3)) g += *gp;
     else if (ps < 0.0 && first) g += inv_alpha;
     if (ok) *gp = g;
   });
@@ -553,7 +577,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
 template <int S>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_assemble_i8_tail(
     const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int NP, int nks_total, int ks0, int nk, int n_chains, int pb32_0,
-    int ntail, int* __restrict__ Tq) {
+    int ntail, int* __restrict__ Tq, I8Delta dl) {
+  if (dl.dsel && i8_delta_slices(*dl.dsel) != S) return;
   const int nCB = nCp / I8_BM;
   const int cb = blockIdx.x % nCB, tb = blockIdx.x / nCB;
   const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -575,7 +600,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 template <int S>
 __global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restrict__ Tq, int pieces, int nCp, int ntail, int pb32_0, int accumulate,
                                                              I8Pairs pr, int n_chains, const int* __restrict__ phase, const int* __restrict__ vbad,
-                                                             int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp) {
+                                                             int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp, I8Delta dl) {
+  if (dl.dsel && i8_delta_slices(*dl.dsel) != S) return;
   const int W = 32 * ntail;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(i / W), j = (int)(i % W);
@@ -590,8 +616,8 @@ __global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restri
   const double val = i8_combine<S>([&](int g) { return acc[g]; });
   const int a = pr.pa[p], b = pr.pb[p];
   double* gp = Gq + (size_t)c * DP * DP + a * DP + b;
-  double gv = (val * pr.scale[p]) * (vbad[c] ? __builtin_nan("") : ldexp(1.0, -vexp[c]));
-  if (accumulate) gv += *gp;
+  double gv = (val * pr.scale[p]) * (vbad[c] ? __builtin_nan("") : ldexp(dl.cscale, -vexp[c]));
+  if ((accumulate & 1) || ((accumulate & 2) && !(dl.rebase && dl.rebase[c]))) gv += *gp;
   else if (a == b) gv += inv_alpha;
   *gp = gv;
 }

@@ -54,6 +54,7 @@ struct Group {
   int fsplit = 1;  // fp64 assembly of small batches: row ranges per chain (planes in Gpart)
   int* vbad = nullptr;
   int* vexp = nullptr;   // per-chain extra binary digits of the v grid (VSlice)
+  int* vexp_d = nullptr; int* rebase = nullptr; unsigned long long* dmax = nullptr;  // delta assembly (VSlice / I8Delta)
   d4* ctile = nullptr;   // c = v(1-2p) of trj.w in the tile layout of k_mompass, [ceil(n/16)][Mp/16][64] x 4 doubles
   int nCp = 0;
 };
@@ -91,6 +92,8 @@ struct rmhmc_ctx {
   bool i8 = false;
   int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
   int i8_inner_drop = 1;     // inner assemblies from S-1 slices (launch_assemble; RMHMC_FLAG_INT8_INNER_FULL / RMHMC_I8_INNER_DROP=0: off)
+  int i8_delta = 1;          // G at the end of a leapfrog step as G(last position iterate) + the assembly of the v differences (RMHMC_I8_DELTA=0: off)
+  int i8_force_rebase = 0;   // (tests: treat every chain as if its v exponent had changed)
   int i8_tail = -1;          // ragged last pair block as tiles of its own: -1 when it pays (launch_assemble_i8_t), 0 never, 1 always
   int8_t* d_Zs = nullptr;
   int* d_ze = nullptr;
@@ -219,8 +222,14 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
     default: { constexpr int S_ = 7, WN_ = 2, TN_ = 1; __VA_ARGS__; } break;       \
   }
 
+// Delta assembly of the evaluation that ends a leapfrog step (I8Delta in metric_i8.hip.h): the last position iterate has left its N in
+// the slice planes and its G - summed from all six slices - in Gq, and v moves by 1e-6 between the two points, so the difference
+// needs four slices (10 slice products) where the full assembly needs six (21).
+static bool use_delta(const rmhmc_ctx* ctx, const Group& g) {
+  return ctx->i8 && ctx->i8_delta && !ctx->big && ctx->i8S == 6 && g.ctile && g.ksplit_a <= 1 && ctx->K >= 2 && g.dmax;
+}
 template <int MODE>
-void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out2 = nullptr) {
+void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out2 = nullptr, bool delta = false) {
   launch(ctx, g, HEAVY, "rowpass", [&](hipStream_t st) {
     if (ctx->big) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
@@ -233,7 +242,13 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
       (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
       const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
       // (with c tiles nobody reads a natural-layout c on this path: k_mompass and k_trvec take the tiles)
-      if (g.ctile && MODE == RP_F) {
+      if (MODE == RP_F && delta) {
+        (void)hipMemsetAsync(g.dmax, 0, sizeof(unsigned long long), st);
+        VSlice vd = vs;
+        vd.vexp_d = g.vexp_d; vd.rebase = g.rebase; vd.dmax = g.dmax; vd.force_rebase = ctx->i8_force_rebase;
+        NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, RP_F, 6, false, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
+                                          out0, nullptr, g.ch.gpart, g.ch.ljl_part, vd, g.ctile, g.ch.cstale));
+      } else if (g.ctile && MODE == RP_F) {
         I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_, false>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
                                                         out0, nullptr, g.ch.gpart, g.ch.ljl_part, vs, g.ctile, g.ch.cstale)));
       } else {
@@ -249,7 +264,13 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
 
 // int8 metric path: cut v into slices, then the sliced GEMM against the fixed slices of x_a x_b (metric_i8.hip.h)
 template <int S, int WN, int TN>
-void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part) {
+void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part, bool delta = false) {
+  // delta: this instantiation on the S least significant V planes, added to Gq if *dmax asks for exactly S planes (I8Delta)
+  const size_t vplane = (size_t)ctx->i8_nks * g.nCp * 32;
+  const int8_t* const Vs = g.Vs + (delta ? (size_t)(ctx->i8S - S) * vplane : 0);
+  const I8Delta dl{delta ? g.dmax : nullptr, delta ? g.rebase : nullptr, delta ? std::ldexp(1.0, -8 * (ctx->i8S - S)) : 1.0};
+  const int* const vexp = delta ? g.vexp_d : g.vexp;
+  const int acc0 = delta ? 2 : 0;
   if (part == 0) {
     hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad,
                        ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp);
@@ -261,7 +282,8 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   if (g.ksplit_a > 1) {  // small batch: too few tiles to fill the chip, so the k range is cut into planes that are summed afterwards
     const size_t plane = (size_t)g.n * ctx->DP * ctx->DP;
     hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_a), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks,
-                       0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane, g.vexp, nPB);
+                       0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane, g.vexp, nPB,
+                       I8Delta{nullptr, nullptr, 1.0});
     hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.Gq, g.Gpart, g.ksplit_a, plane, plane);
     return;
   }
@@ -276,14 +298,14 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   for (int ks0 = 0; ks0 < ctx->i8_nks; ks0 += ctx->i8_chunk) {
     const int nk = std::min(ctx->i8_chunk, ctx->i8_nks - ks0);
     if (nblk_main)
-      hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk_main), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp,
-                         ctx->i8_nks, ks0, nk, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0, g.vexp, npb);
+      hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk_main), dim3(128 * WN), lds, st, Vs, ctx->d_Zs, g.nCp,
+                         ctx->i8_nks, ks0, nk, (ks0 > 0 ? 1 : 0) | acc0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0, vexp, npb, dl);
     if (tail) {
       const int pieces = std::max(1, std::min({g.tail_pieces, nk / 8, (int)(256 / std::max(1, nCB * ntail))}));
-      hipLaunchKernelGGL((k_assemble_i8_tail<S>), dim3((unsigned)(nCB * ntail), (unsigned)pieces), dim3(128), (i8_lds_bytes<S, 1, 1>()), st, g.Vs, ctx->d_Zs,
-                         g.nCp, ctx->pairs.NPp, ctx->pairs.NP, ctx->i8_nks, ks0, nk, g.n, pb32_0, ntail, g.Tq);
+      hipLaunchKernelGGL((k_assemble_i8_tail<S>), dim3((unsigned)(nCB * ntail), (unsigned)pieces), dim3(128), (i8_lds_bytes<S, 1, 1>()), st, Vs, ctx->d_Zs,
+                         g.nCp, ctx->pairs.NPp, ctx->pairs.NP, ctx->i8_nks, ks0, nk, g.n, pb32_0, ntail, g.Tq, dl);
       hipLaunchKernelGGL((k_assemble_i8_tailsum<S>), dim3((unsigned)(((size_t)g.n * 32 * ntail + 255) / 256)), dim3(256), 0, st, g.Tq, pieces, g.nCp, ntail,
-                         pb32_0, ks0 > 0 ? 1 : 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp);
+                         pb32_0, (ks0 > 0 ? 1 : 0) | acc0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, vexp, dl);
     }
   }
 }
@@ -315,7 +337,15 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
 // inner: an assembly whose G only steers a fixed-point iterate (the position iterations before the last, rmhmc.py:116-122).  With
 // ctx->i8_inner_drop it is summed from the S-1 most significant slices of the same operands (balanced digits: dropping the last digit
 // IS rounding to the coarser grid), 15 slice products instead of 21.
-void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = false) {
+void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = false, bool delta = false) {
+  if (ctx->i8 && delta) {  // (use_delta: S = 6, WN = 4)
+    launch(ctx, g, HEAVY, "assemble_i8_delta", [&](hipStream_t st) {
+      launch_assemble_i8_t<6, 4, 1>(ctx, g, v, st, 1, true);
+      launch_assemble_i8_t<5, 4, 1>(ctx, g, v, st, 1, true);
+      launch_assemble_i8_t<4, 4, 1>(ctx, g, v, st, 1, true);
+    });
+    return;
+  }
   if (ctx->i8) {
     if (ctx->big)  // (the generic row pass already wrote the slices)
       launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 0))); });
@@ -447,9 +477,10 @@ void run_phases(rmhmc_ctx* ctx, const std::vector<Phase>& phases) {
 // -> factor / inverse / u = G^-1 p -> quadratic term -> leverage pass (trace term) -> momentum update.
 // mode 0: everything; 1: metric, factor, inverse, gradient, log joint only (simplified mMALA); 2: mode 1 + the trace term (full mMALA)
 void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, int mode = 0) {
-  ph.push_back([ctx](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv2); });
+  // (advance: the evaluation that ends a leapfrog step - the last position iterate's slices and G are at hand)
+  ph.push_back([ctx, advance](Group& g) { launch_rowpass<RP_F>(ctx, g, g.ch.trj.w, g.ch.rv0, g.ch.rv2, advance && use_delta(ctx, g)); });
   if (ctx->big) ph.push_back([ctx](Group& g) { SMALL(ctx, g, "small", k_finish_big, ctx->dd, g.ch, g.nsplit); });
-  ph.push_back([ctx](Group& g) { launch_assemble(ctx, g, g.ch.rv0); });
+  ph.push_back([ctx, advance](Group& g) { launch_assemble(ctx, g, g.ch.rv0, false, advance && use_delta(ctx, g)); });
   if (ctx->big) {
     ph.push_back([ctx](Group& g) {
       if (ctx->want_G)
@@ -787,6 +818,8 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   if (const char* e = getenv("RMHMC_CCACHE")) ctx->ccache = atoi(e) != 0;
   if (const char* e = getenv("RMHMC_CDYN")) ctx->cdyn = atoi(e) != 0;
   if (const char* e = getenv("RMHMC_I8_TAIL")) ctx->i8_tail = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("RMHMC_I8_DELTA")) ctx->i8_delta = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("RMHMC_I8_FORCE_REBASE")) ctx->i8_force_rebase = atoi(e) ? 1 : 0;
   if (flags & RMHMC_FLAG_INT8_INNER_FULL) ctx->i8_inner_drop = 0;
   if (const char* e = getenv("RMHMC_I8_INNER_DROP")) ctx->i8_inner_drop = atoi(e) ? 1 : 0;
   int rc = RMHMC_OK;
@@ -901,6 +934,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         RC(dalloc(ctx, &g.Vs, (size_t)S * ctx->i8_nks * g.nCp * 32));
         RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
         RC(dalloc(ctx, &g.vexp, (size_t)g.nCp));
+        RC(dalloc(ctx, &g.vexp_d, (size_t)g.nCp)); RC(dalloc(ctx, &g.rebase, (size_t)g.nCp)); RC(dalloc(ctx, &g.dmax, (size_t)1));
         RC(dalloc(ctx, &g.Qs, (size_t)S * ctx->i8_nkp * g.nCp * 32));
         RC(dalloc(ctx, &g.qscale, (size_t)g.nCp));
         // small batches: cut the k range so that about 256 workgroups exist (at least 8 stages per piece, at most 16 pieces; only
@@ -932,13 +966,14 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         auto kfn3 = k_assemble_i8_tail<S_>;
         HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
       });
-      if (S == 6)  // the instantiations of the inner assemblies (launch_assemble)
-        I8_SWITCH_S(S - 1, {
-          auto kfn = k_assemble_i8<S_, WN_, TN_>;
-          HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, WN_, TN_>())));
-          auto kfn3 = k_assemble_i8_tail<S_>;
-          HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
-        });
+      if (S == 6)  // the instantiations of the inner assemblies (launch_assemble) and of the delta assembly
+        for (int sv = S - 2; sv < S; ++sv)
+          I8_SWITCH_S(sv, {
+            auto kfn = k_assemble_i8<S_, WN_, TN_>;
+            HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, WN_, TN_>())));
+            auto kfn3 = k_assemble_i8_tail<S_>;
+            HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
+          });
     }
     for (Group& g : ctx->groups) {  // planes of the fp64 small-batch assembly (shared with the int8 k-split planes, whichever is larger)
       const int need = std::max(g.fsplit, g.ksplit_a);
@@ -1092,6 +1127,8 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
     for (size_t a = 0, q = 0; a < D; ++a)
       for (size_t b = 0; b <= a; ++b, ++q)
         bound = std::max(bound, std::ldexp((double)ctx->i8S * (double)M, ze[q] - 8 * ctx->i8S) / std::sqrt(g0[a] * g0[b]));
+    // (delta assembly at the end of a step: the slice products dropped from the difference add to those dropped from the base matrix)
+    if (ctx->i8_delta && ctx->i8S == 6 && !ctx->big) bound *= (2.0 * ctx->i8S - 1.0) / ctx->i8S;
     ctx->i8_bound = bound;
     const bool ok = !(ctx->flags & RMHMC_FLAG_INT8_CERTIFY) || bound <= RMHMC_INT8_CERTIFY_TOL;
     if (!ok && ctx->big && !ctx->d_hpart) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * ctx->n * Mp));
