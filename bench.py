@@ -204,7 +204,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    KT_NAMES = ("assemble", "assemble_i8", "assemble_i8_inner", "assemble_i8_delta", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small",
+    KT_NAMES = ("assemble", "assemble_i8", "assemble_i8_inner", "assemble_i8_inner_delta", "assemble_i8_delta", "vsplit", "leverage", "leverage_i8", "qsplit", "trvec", "rowpass", "mompass", "factor", "small",
                 "fused", "medium", "total")
     # un-timed repetition of the same K steps with HIP events around every launch (on the library's own stream)
     ctx.kernel_time("enable"); ctx.kernel_time("reset")

@@ -496,10 +496,15 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
 // LEAST significant planes as max |N_new - N_old| needs: the instantiations S' = 6, 5, 4 are all launched on the V planes S - S' ..
 // S - 1 (and the Z planes 0 .. S' - 1: the same products i + j < S as the full assembly, minus those with a zero V plane), each
 // reads the maximum the row pass left in *dsel and all but the one whose S' matches return at once.  cscale = 2^-8(S - S').
+// The same for the second position iterate of a step (an inner iterate: its G only steers the next one and is summed from the five
+// most significant planes): G(w_2) = G(w_1) + the planes t .. 4 of N_2 - N_1, S' = 5 (t = 0) when the maximum needs all six digits,
+// S' = 4 (t = 1) otherwise - which is what 8192 chains at stationarity always get (max |v_2 - v_1| = 2^-11.3 +- 0.35 against 2^-9).
 struct I8Delta {
   const unsigned long long* dsel;  // null: ordinary assembly
   const int* rebase;               // chains whose planes hold N_new itself (the exponent of their grid has changed): G is overwritten
   double cscale;
+  int need_lo, need_hi;            // this launch does the work when the digits the maximum needs lie in [need_lo, need_hi]
+  __device__ __forceinline__ bool skip() const;
 };
 // S' balanced digits hold |N| <= 127 (256^S' - 1) / 255 = 0.498 256^S'
 __device__ __forceinline__ int i8_delta_slices(unsigned long long bits) {
@@ -507,6 +512,12 @@ __device__ __forceinline__ int i8_delta_slices(unsigned long long bits) {
   if (mx <= 0.49 * 4294967296.0) return 4;
   if (mx <= 0.49 * 1099511627776.0) return 5;
   return 6;
+}
+
+__device__ __forceinline__ bool I8Delta::skip() const {
+  if (!dsel) return false;
+  const int need = i8_delta_slices(*dsel);
+  return need < need_lo || need > need_hi;
 }
 
 // the assembly proper: lower triangle of G[c] = C[c][:] * scale + I/alpha, natural row-major DP x DP like k_assemble (the
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
                                                           int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
                                                           const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
                                                           size_t plane_stride, const int* __restrict__ vexp, int npb, I8Delta dl) {
-  if (dl.dsel && i8_delta_slices(*dl.dsel) != S) return;
+  if (dl.skip()) return;
   int cb, pb;  // npb: pair blocks of this launch (all of them, or the full ones when k_assemble_i8_tail takes the ragged rest)
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, npb, cb, pb)) return;
   // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow.
@@ -578,7 +589,7 @@ template <int S>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_assemble_i8_tail(
     const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int NP, int nks_total, int ks0, int nk, int n_chains, int pb32_0,
     int ntail, int* __restrict__ Tq, I8Delta dl) {
-  if (dl.dsel && i8_delta_slices(*dl.dsel) != S) return;
+  if (dl.skip()) return;
   const int nCB = nCp / I8_BM;
   const int cb = blockIdx.x % nCB, tb = blockIdx.x / nCB;
   const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -601,7 +612,7 @@ template <int S>
 __global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restrict__ Tq, int pieces, int nCp, int ntail, int pb32_0, int accumulate,
                                                              I8Pairs pr, int n_chains, const int* __restrict__ phase, const int* __restrict__ vbad,
                                                              int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp, I8Delta dl) {
-  if (dl.dsel && i8_delta_slices(*dl.dsel) != S) return;
+  if (dl.skip()) return;
   const int W = 32 * ntail;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(i / W), j = (int)(i % W);

@@ -93,6 +93,7 @@ struct rmhmc_ctx {
   int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
   int i8_inner_drop = 1;     // inner assemblies from S-1 slices (launch_assemble; RMHMC_FLAG_INT8_INNER_FULL / RMHMC_I8_INNER_DROP=0: off)
   int i8_delta = 1;          // G at the end of a leapfrog step as G(last position iterate) + the assembly of the v differences (RMHMC_I8_DELTA=0: off)
+  int i8_delta_inner = 1;    // the second position iterate likewise, from the first (RMHMC_I8_DELTA_INNER=0: off)
   int i8_force_rebase = 0;   // (tests: treat every chain as if its v exponent had changed)
   int i8_tail = -1;          // ragged last pair block as tiles of its own: -1 when it pays (launch_assemble_i8_t), 0 never, 1 always
   int8_t* d_Zs = nullptr;
@@ -228,6 +229,11 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
 static bool use_delta(const rmhmc_ctx* ctx, const Group& g) {
   return ctx->i8 && ctx->i8_delta && !ctx->big && ctx->i8S == 6 && g.ctile && g.ksplit_a <= 1 && ctx->K >= 2 && g.dmax;
 }
+// The second position iterate as a delta of the first (both inner iterates on five slices: it = 2 < K - 1; later inner iterates would need
+// the N of a predecessor whose planes hold differences)
+static bool use_delta_inner(const rmhmc_ctx* ctx, const Group& g, int it) {
+  return use_delta(ctx, g) && ctx->i8_delta_inner && ctx->i8_inner_drop && it == 2 && it < ctx->K - 1;
+}
 template <int MODE>
 void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out2 = nullptr, bool delta = false) {
   launch(ctx, g, HEAVY, "rowpass", [&](hipStream_t st) {
@@ -242,12 +248,17 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
       (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
       const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
       // (with c tiles nobody reads a natural-layout c on this path: k_mompass and k_trvec take the tiles)
-      if (MODE == RP_F && delta) {
+      if (MODE != RP_G && delta) {
         (void)hipMemsetAsync(g.dmax, 0, sizeof(unsigned long long), st);
         VSlice vd = vs;
         vd.vexp_d = g.vexp_d; vd.rebase = g.rebase; vd.dmax = g.dmax; vd.force_rebase = ctx->i8_force_rebase;
-        NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, RP_F, 6, false, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
-                                          out0, nullptr, g.ch.gpart, g.ch.ljl_part, vd, g.ctile, g.ch.cstale));
+        if (MODE == RP_F) {
+          NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, RP_F, 6, false, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
+                                            out0, nullptr, g.ch.gpart, g.ch.ljl_part, vd, g.ctile, g.ch.cstale));
+        } else {
+          NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, RP_V, 6, true, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
+                                            out0, out2, g.ch.gpart, g.ch.ljl_part, vd, g.ctile, g.ch.cstale));
+        }
       } else if (g.ctile && MODE == RP_F) {
         I8_SWITCH(ctx, NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, MODE, S_, false>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
                                                         out0, nullptr, g.ch.gpart, g.ch.ljl_part, vs, g.ctile, g.ch.cstale)));
@@ -264,11 +275,13 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
 
 // int8 metric path: cut v into slices, then the sliced GEMM against the fixed slices of x_a x_b (metric_i8.hip.h)
 template <int S, int WN, int TN>
-void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part, bool delta = false) {
-  // delta: this instantiation on the S least significant V planes, added to Gq if *dmax asks for exactly S planes (I8Delta)
+void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t st, int part, bool delta = false, int seff = 6, int need_lo = 0,
+                          int need_hi = 0) {
+  // delta: this instantiation on the V planes seff - S .. seff - 1 (seff = 6: all digits count; 5: an inner iterate), added to Gq if the
+  // digits *dmax asks for lie in [need_lo, need_hi] (I8Delta)
   const size_t vplane = (size_t)ctx->i8_nks * g.nCp * 32;
-  const int8_t* const Vs = g.Vs + (delta ? (size_t)(ctx->i8S - S) * vplane : 0);
-  const I8Delta dl{delta ? g.dmax : nullptr, delta ? g.rebase : nullptr, delta ? std::ldexp(1.0, -8 * (ctx->i8S - S)) : 1.0};
+  const int8_t* const Vs = g.Vs + (delta ? (size_t)(seff - S) * vplane : 0);
+  const I8Delta dl{delta ? g.dmax : nullptr, delta ? g.rebase : nullptr, delta ? std::ldexp(1.0, -8 * (seff - S)) : 1.0, need_lo, need_hi};
   const int* const vexp = delta ? g.vexp_d : g.vexp;
   const int acc0 = delta ? 2 : 0;
   if (part == 0) {
@@ -283,7 +296,7 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
     const size_t plane = (size_t)g.n * ctx->DP * ctx->DP;
     hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_a), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks,
                        0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane, g.vexp, nPB,
-                       I8Delta{nullptr, nullptr, 1.0});
+                       I8Delta{nullptr, nullptr, 1.0, 0, 0});
     hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.Gq, g.Gpart, g.ksplit_a, plane, plane);
     return;
   }
@@ -338,11 +351,18 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
 // ctx->i8_inner_drop it is summed from the S-1 most significant slices of the same operands (balanced digits: dropping the last digit
 // IS rounding to the coarser grid), 15 slice products instead of 21.
 void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = false, bool delta = false) {
+  if (ctx->i8 && delta && inner) {  // (use_delta_inner: five-slice accuracy)
+    launch(ctx, g, HEAVY, "assemble_i8_inner_delta", [&](hipStream_t st) {
+      launch_assemble_i8_t<5, 4, 1>(ctx, g, v, st, 1, true, 5, 6, 6);
+      launch_assemble_i8_t<4, 4, 1>(ctx, g, v, st, 1, true, 5, 4, 5);
+    });
+    return;
+  }
   if (ctx->i8 && delta) {  // (use_delta: S = 6, WN = 4)
     launch(ctx, g, HEAVY, "assemble_i8_delta", [&](hipStream_t st) {
-      launch_assemble_i8_t<6, 4, 1>(ctx, g, v, st, 1, true);
-      launch_assemble_i8_t<5, 4, 1>(ctx, g, v, st, 1, true);
-      launch_assemble_i8_t<4, 4, 1>(ctx, g, v, st, 1, true);
+      launch_assemble_i8_t<6, 4, 1>(ctx, g, v, st, 1, true, 6, 6, 6);
+      launch_assemble_i8_t<5, 4, 1>(ctx, g, v, st, 1, true, 6, 5, 5);
+      launch_assemble_i8_t<4, 4, 1>(ctx, g, v, st, 1, true, 6, 4, 4);
     });
     return;
   }
@@ -555,8 +575,8 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_pos_first, D, DP, g.ch, eps); });
   }
   for (int it = 1; it < K; ++it) {
-    ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0); });
-    ph.push_back([=](Group& g) { launch_assemble(ctx, g, g.ch.rv0, it < K - 1); });
+    ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0, nullptr, use_delta_inner(ctx, g, it)); });
+    ph.push_back([=](Group& g) { launch_assemble(ctx, g, g.ch.rv0, it < K - 1, use_delta_inner(ctx, g, it)); });
     if (ctx->big)
       ph.push_back([=](Group& g) { BIG(ctx, g, "factor", k_chol_big<0>, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096, eps); });
     else
@@ -819,6 +839,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   if (const char* e = getenv("RMHMC_CDYN")) ctx->cdyn = atoi(e) != 0;
   if (const char* e = getenv("RMHMC_I8_TAIL")) ctx->i8_tail = atoi(e) ? 1 : 0;
   if (const char* e = getenv("RMHMC_I8_DELTA")) ctx->i8_delta = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("RMHMC_I8_DELTA_INNER")) ctx->i8_delta_inner = atoi(e) ? 1 : 0;
   if (const char* e = getenv("RMHMC_I8_FORCE_REBASE")) ctx->i8_force_rebase = atoi(e) ? 1 : 0;
   if (flags & RMHMC_FLAG_INT8_INNER_FULL) ctx->i8_inner_drop = 0;
   if (const char* e = getenv("RMHMC_I8_INNER_DROP")) ctx->i8_inner_drop = atoi(e) ? 1 : 0;

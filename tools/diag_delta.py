@@ -11,14 +11,15 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 hip = _capi.load_hip_library(); oracle = _capi.RmhmcLib(ge.ORACLE_LIB)
-for (M, D, n) in [(97, 64, 129), (203, 33, 7), (900, 64, 2100)]:
+for (M, D, n) in [(129, 48, 300), (203, 33, 7), (900, 64, 2100), (400, 40, 2432), (10000, 64, 1024)]:
     XX, t = synthetic_logreg(M, D, 5)
     rs = np.random.RandomState(M + n)
     w = 0.4 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
     dirs = np.where(rs.rand(n) < 0.5, -1, 1).astype(np.int32)
     for ns in (1, 2, 3):
         res = {}
-        for name, env, fl in (("full", {"RMHMC_I8_DELTA": "0"}, 0), ("delta", {"RMHMC_I8_DELTA": "1"}, 0),
+        for name, env, fl in (("full", {"RMHMC_I8_DELTA": "0"}, 0), ("delta", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "1"}, 0),
+                              ("delta_end", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "0"}, 0),
                               ("full_innerfull", {"RMHMC_I8_DELTA": "0"}, _capi.FLAG_INT8_INNER_FULL), ("fp64", {}, None)):
             os.environ.update(env)
             flags = 0 if fl is None else (_capi.int8_metric_flags(6) | fl)
@@ -31,6 +32,6 @@ for (M, D, n) in [(97, 64, 129), (203, 33, 7), (900, 64, 2100)]:
             ref = ctx.leapfrog(w[:nn], p[:nn], 0.5, dirs[:nn], ns, 4)
         def mx(a, b, m=n):
             return max(rel(a[0][c], b[0][c]) for c in range(m))
-        print(M, D, n, "steps", ns, "delta-full %.1e  innerfull-full %.1e  fp64-full %.1e | vs oracle: full %.1e delta %.1e fp64 %.1e | max|theta| %.1e"
-              % (mx(res["delta"], res["full"]), mx(res["full_innerfull"], res["full"]), mx(res["fp64"], res["full"]),
+        print(M, D, n, "steps", ns, "delta_end-full %.1e delta-full %.1e  innerfull-full %.1e  fp64-full %.1e | vs oracle: full %.1e delta %.1e fp64 %.1e | max|theta| %.1e"
+              % (mx(res["delta_end"], res["full"]), mx(res["delta"], res["full"]), mx(res["full_innerfull"], res["full"]), mx(res["fp64"], res["full"]),
                  mx(res["full"], ref, nn), mx(res["delta"], ref, nn), mx(res["fp64"], ref, nn), np.abs(res["full"][0]).max()), flush=True)
