@@ -368,8 +368,8 @@ def main():
             "dtype_detail": ("f64 throughout; the two O(M D^2) contractions (metric assembly, leverages) as exact integer GEMMs: operands cut into %d "
                              "signed-byte slices, int8 MFMA with int32 accumulation, combined in f64 (G to ~2e-14 of the f64 oracle at 6 slices)%s"
                              % (args.i8_slices, "; the metric of the position fixed-point iterates before the last (it only steers the next iterate) "
-                                "from the 5 most significant slices (effect on theta after a step < 1e-11); the metric at the end of a step as G(last iterate) + the "
-                                "exact integer GEMM of the v differences (4-6 slices as their size needs, identical grids)" if args.i8_slices == 6 else ""))
+                                "from the 5 most significant slices (effect on theta after a step < 1e-11); the metric at the end of a step and that of the second position iterate as the "
+                                "predecessor's G + the exact integer GEMM of the v differences (4-6 slices as their size needs, identical grids)" if args.i8_slices == 6 else ""))
                             if args.i8_slices else "f64 throughout (fp64 matrix cores)",
             "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
