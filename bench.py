@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--burn-in-steps", type=int, default=-1,
                     help="untimed global leapfrog steps between chains_init and the warmup, so that the timed steps run on chains at "
                          "stationarity (the metric's window is the post-burn-in sampling phase, rmhmc.py:194-198).  Default: 300 for the "
-                         "large batched workloads (about 85 transitions), 0 otherwise; alternates.cold_start times the first steps from theta0")
+                         "large batched workloads (about 85 transitions; 80 at D > 64), 0 otherwise; alternates.cold_start times the first steps from theta0")
     ap.add_argument("--no-fp64-roofline", action="store_true", help="skip the extra fp64-matrix-core run behind roofline_fp64")
     args = ap.parse_args()
 
@@ -181,7 +181,8 @@ def main():
         args.i8_slices = 0
     ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
     if args.burn_in_steps < 0:
-        args.burn_in_steps = 300 if (8 < D <= 64 and n * float(M) * D * D >= 1e9) else 0
+        big_batch = 8 < D <= 256 and n * float(M) * D * D >= 1e9
+        args.burn_in_steps = (300 if D <= 64 else 80) if big_batch else 0   # (config 5: 0.5 s per global step)
     if args.burn_in_steps:
         ctx.chains_run(args.burn_in_steps)   # untimed: from theta0 = 1e-3 (rmhmc.py:27) to stationarity
 

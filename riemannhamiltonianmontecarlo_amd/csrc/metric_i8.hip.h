@@ -418,12 +418,23 @@ __global__ __launch_bounds__(256) void k_zsplit(const double* __restrict__ Xt, i
 // chain: per stage the 8 chains' bytes are 256 contiguous bytes of every slice plane.  A non-finite v (diverged chain) raises
 // vbad[c], which turns the chain's G into NaN in the epilogue exactly as it would be in floating point.  Also writes the identity
 // padding of G.
-template <int S>
+// DELTA (large-D path, see I8Delta below): the planes hold N_old of the previous position iterate; they get the digits of N_new - N_old,
+// vexp is only read (the chain's exponent goes to vd.vexp_d, a changed one marks the chain in vd.rebase and its planes get N_new
+// itself), max |N_new - N_old| of the launch goes to *vd.dmax.
+struct VDelta {
+  int* vexp_d;
+  int* rebase;
+  unsigned long long* dmax;
+  int force_rebase;
+};
+template <int S, bool DELTA = false>
 __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow, int Mp, int n_chains, const int* __restrict__ phase, int nks,
                                                 int nCp, int8_t* __restrict__ Vs, int* __restrict__ vbad, int D, int DP, double inv_alpha,
-                                                double* __restrict__ Gq, int* __restrict__ vexp) {
+                                                double* __restrict__ Gq, int* __restrict__ vexp, VDelta vd = VDelta{}) {
   __shared__ int sbad[8];
   __shared__ unsigned long long smax[8];
+  __shared__ unsigned long long sdmax;
+  if (DELTA && threadIdx.x == 0) sdmax = 0ull;
   const int t = threadIdx.x;
   const int cl = (t >> 3) & 7, k4 = t & 7, ksl = t >> 6;
   const int c = blockIdx.x * 8 + cl;
@@ -449,8 +460,15 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
     const double mx = __longlong_as_double((long long)smax[cl]);
     int e = 0;
     if (mx > 0.0) { (void)frexp(mx, &e); vsh = min(900, max(0, -2 - e)); }
-    if (live && k4 == 0 && ksl == 0) vexp[c] = vsh;
+    if constexpr (DELTA) {
+      if (live && k4 == 0 && ksl == 0) { vd.vexp_d[c] = vsh; vd.rebase[c] = (vsh != vexp[c] || vd.force_rebase) ? 1 : 0; }
+    } else {
+      if (live && k4 == 0 && ksl == 0) vexp[c] = vsh;
+    }
   }
+  bool rebase = false;
+  double dmx = 0.0;
+  if constexpr (DELTA) rebase = live && (vsh != vexp[c] || vd.force_rebase);
   int bad = 0;
   if (live) {
     const double* v = vrow + (size_t)c * Mp;
@@ -461,12 +479,28 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
       int w[S];
 #pragma unroll
       for (int s = 0; s < S; ++s) w[s] = 0;
+      long long No[4] = {0, 0, 0, 0};
+      if constexpr (DELTA) {
+        if (!rebase) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) {  // most significant plane first: N = sum_s digit_s 256^(S-1-s)
+            const int wo = *(const int*)(Vs + (((size_t)s * nks + ks) * nCp + c) * 32 + 4 * k4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) No[k] = No[k] * 256 + (long long)(signed char)((wo >> (8 * k)) & 0xFF);
+          }
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         double x = x4[k];
         if (!(x >= 0.0 && x <= 0.25)) { bad = 1; x = 0.0; }
         int d[S];
-        split_digits<S>((long long)rint(ldexp(x, 8 * S + vsh)), d);
+        long long N = (long long)rint(ldexp(x, 8 * S + vsh));
+        if constexpr (DELTA) {
+          N -= No[k];
+          dmx = fmax(dmx, fabs((double)N));
+        }
+        split_digits<S>(N, d);
 #pragma unroll
         for (int s = 0; s < S; ++s) w[s] |= (d[S - 1 - s] & 0xFF) << (8 * k);
       }
@@ -475,7 +509,9 @@ __global__ __launch_bounds__(256) void k_vsplit(const double* __restrict__ vrow,
     }
   }
   if (bad) atomicOr(&sbad[cl], 1);
+  if (DELTA && dmx > 0.0) atomicMax(&sdmax, (unsigned long long)__double_as_longlong(dmx));
   __syncthreads();
+  if (DELTA && t == 0 && sdmax) atomicMax(vd.dmax, sdmax);
   if (t < 8 && blockIdx.x * 8 + t < n_chains && phase[blockIdx.x * 8 + t] == 1) vbad[blockIdx.x * 8 + t] = sbad[t];
   // padding rows D..DP-1 of G (lower triangle): the GEMM writes pairs below D only, and the blocked factorisation of the large-D
   // path runs over all DP rows and uses Gq as a workspace in between, so the identity padding is renewed with every assembly
@@ -504,6 +540,7 @@ struct I8Delta {
   const int* rebase;               // chains whose planes hold N_new itself (the exponent of their grid has changed): G is overwritten
   double cscale;
   int need_lo, need_hi;            // this launch does the work when the digits the maximum needs lie in [need_lo, need_hi]
+  const double* Gbase;             // the matrix that is added to (null: Gq itself; the large-D path factors Gq in place and keeps a copy)
   __device__ __forceinline__ bool skip() const;
 };
 // S' balanced digits hold |N| <= 127 (256^S' - 1) / 255 = 0.498 256^S'
@@ -572,7 +609,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
     double* gp = Gout + (size_t)min(c, n_chains - 1) * DP * DP + max(off, 0);
     double g = (val * fabs(ps)) * s_cmul[ci];
     // accumulate bit 0: a later piece of a long data set; bit 1: delta assembly (all chains but the re-based ones)
-    if ((accumulate & 1) || ((accumulate & 2) && s_coff[ci] != 3)) g += *gp;
+    if (accumulate & 1) g += *gp;
+    else if ((accumulate & 2) && s_coff[ci] != 3) g += dl.Gbase ? dl.Gbase[(size_t)min(c, n_chains - 1) * DP * DP + max(off, 0)] : *gp;
     else if (ps < 0.0 && first) g += inv_alpha;
     if (ok) *gp = g;
   });
@@ -628,7 +666,8 @@ __global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restri
   const int a = pr.pa[p], b = pr.pb[p];
   double* gp = Gq + (size_t)c * DP * DP + a * DP + b;
   double gv = (val * pr.scale[p]) * (vbad[c] ? __builtin_nan("") : ldexp(dl.cscale, -vexp[c]));
-  if ((accumulate & 1) || ((accumulate & 2) && !(dl.rebase && dl.rebase[c]))) gv += *gp;
+  if (accumulate & 1) gv += *gp;
+  else if ((accumulate & 2) && !(dl.rebase && dl.rebase[c])) gv += dl.Gbase ? dl.Gbase[(size_t)c * DP * DP + a * DP + b] : *gp;
   else if (a == b) gv += inv_alpha;
   *gp = gv;
 }

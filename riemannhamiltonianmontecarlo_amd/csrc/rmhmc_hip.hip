@@ -55,6 +55,7 @@ struct Group {
   int* vbad = nullptr;
   int* vexp = nullptr;   // per-chain extra binary digits of the v grid (VSlice)
   int* vexp_d = nullptr; int* rebase = nullptr; unsigned long long* dmax = nullptr;  // delta assembly (VSlice / I8Delta)
+  double* Gbase = nullptr;  // large-D path: copy of the G a delta assembly adds to (Gq is factored in place)
   d4* ctile = nullptr;   // c = v(1-2p) of trj.w in the tile layout of k_mompass, [ceil(n/16)][Mp/16][64] x 4 doubles
   int nCp = 0;
 };
@@ -227,7 +228,7 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
 // the slice planes and its G - summed from all six slices - in Gq, and v moves by 1e-6 between the two points, so the difference
 // needs four slices (10 slice products) where the full assembly needs six (21).
 static bool use_delta(const rmhmc_ctx* ctx, const Group& g) {
-  return ctx->i8 && ctx->i8_delta && !ctx->big && ctx->i8S == 6 && g.ctile && g.ksplit_a <= 1 && ctx->K >= 2 && g.dmax;
+  return ctx->i8 && ctx->i8_delta && (!ctx->big || g.Gbase) && ctx->i8S == 6 && g.ctile && g.ksplit_a <= 1 && ctx->K >= 2 && g.dmax;
 }
 // The second position iterate as a delta of the first (both inner iterates on five slices: it = 2 < K - 1; later inner iterates would need
 // the N of a predecessor whose planes hold differences)
@@ -281,12 +282,19 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   // digits *dmax asks for lie in [need_lo, need_hi] (I8Delta)
   const size_t vplane = (size_t)ctx->i8_nks * g.nCp * 32;
   const int8_t* const Vs = g.Vs + (delta ? (size_t)(seff - S) * vplane : 0);
-  const I8Delta dl{delta ? g.dmax : nullptr, delta ? g.rebase : nullptr, delta ? std::ldexp(1.0, -8 * (seff - S)) : 1.0, need_lo, need_hi};
+  const I8Delta dl{delta ? g.dmax : nullptr, delta ? g.rebase : nullptr, delta ? std::ldexp(1.0, -8 * (seff - S)) : 1.0, need_lo, need_hi,
+                   (delta && ctx->big) ? g.Gbase : nullptr};
   const int* const vexp = delta ? g.vexp_d : g.vexp;
   const int acc0 = delta ? 2 : 0;
   if (part == 0) {
+    if (delta) {  // (large-D path: the planes hold N of the previous iterate, they get the digits of the difference)
+      (void)hipMemsetAsync(g.dmax, 0, sizeof(unsigned long long), st);
+      hipLaunchKernelGGL((k_vsplit<S, true>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs,
+                         g.vbad, ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp, VDelta{g.vexp_d, g.rebase, g.dmax, ctx->i8_force_rebase});
+      return;
+    }
     hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad,
-                       ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp);
+                       ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp, VDelta{});
     return;
   }
   const int nCB = g.nCp / I8_BM, nPB = ctx->pairs.NPp / (32 * TN * WN);
@@ -296,7 +304,7 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
     const size_t plane = (size_t)g.n * ctx->DP * ctx->DP;
     hipLaunchKernelGGL((k_assemble_i8<S, WN, TN>), dim3(nblk, (unsigned)g.ksplit_a), dim3(128 * WN), lds, st, g.Vs, ctx->d_Zs, g.nCp, ctx->i8_nks,
                        0, ctx->i8_nks, 0, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.Gpart, plane, g.vexp, nPB,
-                       I8Delta{nullptr, nullptr, 1.0, 0, 0});
+                       I8Delta{nullptr, nullptr, 1.0, 0, 0, nullptr});
     hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g.ch.Gq, g.Gpart, g.ksplit_a, plane, plane);
     return;
   }
@@ -350,7 +358,10 @@ void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
 // inner: an assembly whose G only steers a fixed-point iterate (the position iterations before the last, rmhmc.py:116-122).  With
 // ctx->i8_inner_drop it is summed from the S-1 most significant slices of the same operands (balanced digits: dropping the last digit
 // IS rounding to the coarser grid), 15 slice products instead of 21.
-void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = false, bool delta = false) {
+// keep_base (large-D path): this G is the base of a delta assembly to come; Gq will be factored in place, so a copy is kept
+void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = false, bool delta = false, bool keep_base = false) {
+  if (ctx->i8 && delta && ctx->big)
+    launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { launch_assemble_i8_t<6, 4, 1>(ctx, g, v, st, 0, true); });
   if (ctx->i8 && delta && inner) {  // (use_delta_inner: five-slice accuracy)
     launch(ctx, g, HEAVY, "assemble_i8_inner_delta", [&](hipStream_t st) {
       launch_assemble_i8_t<5, 4, 1>(ctx, g, v, st, 1, true, 5, 6, 6);
@@ -370,7 +381,11 @@ void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = fal
     if (ctx->big)  // (the generic row pass already wrote the slices)
       launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 0))); });
     const int suse = (inner && ctx->i8_inner_drop && ctx->i8S == 6) ? 5 : ctx->i8S;  // (5 -> 4 costs parity: 2e-9 on theta at M = 97)
-    launch(ctx, g, HEAVY, suse == ctx->i8S ? "assemble_i8" : "assemble_i8_inner", [&](hipStream_t st) { I8_SWITCH_S(suse, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 1))); });
+    launch(ctx, g, HEAVY, suse == ctx->i8S ? "assemble_i8" : "assemble_i8_inner", [&](hipStream_t st) {
+      I8_SWITCH_S(suse, (launch_assemble_i8_t<S_, WN_, TN_>(ctx, g, v, st, 1)));
+      if (keep_base && ctx->big && g.Gbase)
+        (void)hipMemcpyAsync(g.Gbase, g.ch.Gq, sizeof(double) * (size_t)g.n * ctx->DP * ctx->DP, hipMemcpyDeviceToDevice, st);
+    });
     return;
   }
   launch(ctx, g, HEAVY, "assemble", [&](hipStream_t st) {
@@ -576,7 +591,10 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   }
   for (int it = 1; it < K; ++it) {
     ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0, nullptr, use_delta_inner(ctx, g, it)); });
-    ph.push_back([=](Group& g) { launch_assemble(ctx, g, g.ch.rv0, it < K - 1, use_delta_inner(ctx, g, it)); });
+    ph.push_back([=](Group& g) {
+      const bool base = (it == 1 && use_delta_inner(ctx, g, 2)) || (it == K - 1 && use_delta(ctx, g));
+      launch_assemble(ctx, g, g.ch.rv0, it < K - 1, use_delta_inner(ctx, g, it), base);
+    });
     if (ctx->big)
       ph.push_back([=](Group& g) { BIG(ctx, g, "factor", k_chol_big<0>, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096, eps); });
     else
@@ -956,6 +974,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
         RC(dalloc(ctx, &g.vexp, (size_t)g.nCp));
         RC(dalloc(ctx, &g.vexp_d, (size_t)g.nCp)); RC(dalloc(ctx, &g.rebase, (size_t)g.nCp)); RC(dalloc(ctx, &g.dmax, (size_t)1));
+        if (ctx->big && ctx->i8_delta && S == 6) RC(dalloc(ctx, &g.Gbase, (size_t)g.n * ctx->DP * ctx->DP));
         RC(dalloc(ctx, &g.Qs, (size_t)S * ctx->i8_nkp * g.nCp * 32));
         RC(dalloc(ctx, &g.qscale, (size_t)g.nCp));
         // small batches: cut the k range so that about 256 workgroups exist (at least 8 stages per piece, at most 16 pieces; only
@@ -1149,7 +1168,7 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
       for (size_t b = 0; b <= a; ++b, ++q)
         bound = std::max(bound, std::ldexp((double)ctx->i8S * (double)M, ze[q] - 8 * ctx->i8S) / std::sqrt(g0[a] * g0[b]));
     // (delta assembly at the end of a step: the slice products dropped from the difference add to those dropped from the base matrix)
-    if (ctx->i8_delta && ctx->i8S == 6 && !ctx->big) bound *= (2.0 * ctx->i8S - 1.0) / ctx->i8S;
+    if (ctx->i8_delta && ctx->i8S == 6) bound *= (2.0 * ctx->i8S - 1.0) / ctx->i8S;
     ctx->i8_bound = bound;
     const bool ok = !(ctx->flags & RMHMC_FLAG_INT8_CERTIFY) || bound <= RMHMC_INT8_CERTIFY_TOL;
     if (!ok && ctx->big && !ctx->d_hpart) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * ctx->n * Mp));

@@ -214,7 +214,9 @@ def test_inner_iterates_from_five_slices(hip, oracle, M, D, n):
 
 # (shapes whose assembly is one launch over all data rows: with a k split - few tiles, many rows - the library keeps the full assembly)
 # (not M = 97 < 2 D: its third step diverges to |theta| ~ 1e16 and multiplies ANY rounding difference by 1e5 - tools/diag_delta.py)
-@pytest.mark.parametrize("M,D,n", [(900, 64, 2100), (203, 33, 7), (400, 40, 2432), (129, 48, 300)])
+# (D > 64: the large-D path, whose slices are cut by k_vsplit and whose base matrix is a copy - Gq is factored in place)
+@pytest.mark.parametrize("M,D,n", [(900, 64, 2100), (203, 33, 7), (400, 40, 2432), (129, 48, 300), (600, 96, 140), (900, 130, 260),
+                                   (1200, 256, 130)])
 def test_delta_assembly_at_the_end_of_a_step(hip, oracle, monkeypatch, M, D, n):
     """The metric of the evaluation that ends a leapfrog step is G(last position iterate) plus the assembly of the DIFFERENCE of
     the two v vectors, cut into as few slices as its largest element needs (launch_assemble / I8Delta; RMHMC_I8_DELTA=0 turns it
