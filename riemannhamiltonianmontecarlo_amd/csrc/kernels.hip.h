@@ -55,6 +55,9 @@ struct Chains {
   int *steps_left, *phase, *status, *nsteps_last;
   int* cstale;  // 1: the chain's c tiles (ctile) are not those of trj.w - set when a proposal is rejected (trj falls back to cur), cleared by
                 // the row pass of the next evaluation; k_mompass<.., 3> recomputes the tiles of a wave that holds such a chain
+  // chains that have just rejected a proposal (k_iter_end appends, k_crestore at the start of the next step recomputes their c tiles
+  // and empties the list); null where no c tiles are kept
+  int *stale_list, *stale_count;
   long long *iter, *accepted, *steps_done;
   // scratch
   double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv2, *ljl_part, *qpart, *gpart;
@@ -851,6 +854,72 @@ __global__ __launch_bounds__(256, 2) void k_mompass(DevData dd, int n_chains, in
   }
 }
 
+// c tiles of the chains that have just rejected a proposal (Chains::stale_list), 16 of them to a wavefront whatever their place in the
+// batch.  k_mompass<.., 3> recomputes the tiles of every wavefront that holds ONE stale chain: with 3.7 % of the chains stale at a step
+// that is 45 % of its wavefronts (617 us against 460 with none stale); here the same products and the same element-wise expression (same
+// bits) run for the ~300 stale chains alone - ~19 wavefront groups, the rows cut into gridDim.y pieces of their own so that so few
+// wavefronts still finish in microseconds - and the pass that follows finds every flag cleared.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void k_crestore(DevData dd, int n_chains, const int* __restrict__ phase,
+                                                  const double* __restrict__ wq, d4* __restrict__ ctile, int* __restrict__ cstale,
+                                                  const int* __restrict__ list, const int* __restrict__ count) {
+  constexpr int DP = 16 * NB;
+  constexpr int KK = DP / 4;
+  const int lane = threadIdx.x & 63;
+  const int g16 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const int cnt = min(*count, n_chains);
+  if (g16 >= cnt) return;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int rr = lane >> 4, ci = lane & 15;
+  const int chn = list[min(g16 + ci, cnt - 1)];
+  const int cj = min(max(chn, 0), n_chains - 1);
+  const bool live = g16 + ci < cnt && chn >= 0 && chn < n_chains && phase[cj] == 1;
+  double Wb[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
+  const int nb16 = dd.Mp / 16, nb32 = dd.Mp / 32;
+  const int per = (nb32 + nsplit - 1) / nsplit;
+  const int B0 = split * per, B1 = min(nb32, B0 + per);
+  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + 2 * rm_perm16(ci);
+  // the chain's slot in its own 16-chain tile group: lane (rr, chain & 15)
+  d4* __restrict__ ct = ctile + (size_t)(cj >> 4) * nb16 * 64 + rr * 16 + (cj & 15);
+  // (all sixteen operand loads of a block in flight together, the next block's behind this block's element-wise work: left to the
+  //  compiler the loop was one load - one product pair at a time, 40 registers and ~20 us per block)
+  d2 A[KK];
+  auto load_a = [&](int B) {
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) A[kk] = *(const d2*)(xt_p + (size_t)(4 * kk) * dd.Mp + B * 32);
+  };
+  if (B0 < B1) load_a(B0);
+  for (int B = B0; B < B1; ++B) {
+    d4 FA = (d4){0.0, 0.0, 0.0, 0.0}, FB = FA;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      FA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, Wb[kk], FA, 0, 0, 0);
+      FB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, Wb[kk], FB, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (B + 1 < B1) load_a(B + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    d4 cA, cB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // (the expression of mompass_body / k_rowpass: the same bits)
+      const double ea = exp(-FA[r]);
+      const double pa = 1.0 / (1.0 + ea);
+      cA[r] = pa * (1.0 - pa) * (1.0 - 2.0 * pa);
+      const double eb = exp(-FB[r]);
+      const double pb = 1.0 / (1.0 + eb);
+      cB[r] = pb * (1.0 - pb) * (1.0 - 2.0 * pb);
+    }
+    if (live) {
+      ct[(size_t)(2 * B) * 64] = cA;
+      ct[(size_t)(2 * B + 1) * 64] = cB;
+    }
+  }
+  if (live && rr == 0 && split == 0) cstale[cj] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4  leverage pass on the matrix cores: h_n = x_n' G^-1 x_n for every data row, then
 //       tr_d = sum_n c_n h_n x_nd          (= tr(G^-1 dG/dw_d),      rmhmc.py:67-77,148-156)
@@ -1596,7 +1665,10 @@ __device__ __forceinline__ void iter_end_dev(int D, int DP, const Chains& ch, co
   if (lane == 0) {
     ch.Hprop[c] = Hp;
     if (accept) ch.accepted[c] += 1;
-    else if (ch.cstale) ch.cstale[c] = 1;
+    else if (ch.cstale) {
+      ch.cstale[c] = 1;
+      if (ch.stale_list) ch.stale_list[atomicAdd(ch.stale_count, 1)] = c;
+    }
     ch.iter[c] = it + 1;
     ch.phase[c] = 0;
     if (it + 1 == ip.iter_limit && ip.done_count) atomicAdd(ip.done_count, 1);

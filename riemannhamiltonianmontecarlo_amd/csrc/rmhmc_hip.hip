@@ -86,6 +86,7 @@ struct rmhmc_ctx {
   size_t fused_lds = 0;
   bool medium = false;       // one-launch leapfrog step for small batches with 8 < D <= 32 (medium_step.hip.h)
   size_t medium_lds = 0;
+  bool crestore = true;      // c tiles of the chains that have just rejected recomputed by k_crestore, 16 to a wavefront (RMHMC_CRESTORE=0: k_mompass<.., 3> alone)
   bool cdyn = true;          // first momentum pass of a step re-uses the c tiles of chains that did not just reject (RMHMC_CDYN=0: always recomputes)
   bool ccache = true;        // c = v(1-2p) kept per position in the momentum pass's tile layout (RMHMC_CCACHE=0: recomputed every pass)
   bool hmc_traj = false;     // plain HMC in small batches: one launch per trajectory (k_hmc_traj)
@@ -575,6 +576,21 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     });
     return;
   }
+  // c tiles of the chains whose last proposal was rejected (their trj has fallen back to cur): recomputed for them alone, so that the
+  // first momentum pass finds every chain's tiles at hand
+  if (!ctx->big && ctx->cdyn)
+    ph.push_back([=](Group& g) {
+      if (!g.ctile || !g.ch.stale_list) return;
+      launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
+        const int rsplit = std::max(1, std::min(64, ctx->Mp / 32 / 4));  // (row pieces of this kernel's own: few wavefronts, short pieces)
+        // (room for 2048 rejected chains; any beyond stay flagged and k_mompass<.., 3> recomputes their wavefronts as before.  A grid for
+        //  the whole batch spent 100 us launching 8192 workgroups of which ~5 % had work.)
+        dim3 grid((unsigned)std::min((g.n + 63) / 64, 32), (unsigned)rsplit);
+        NB_SWITCH(ctx, hipLaunchKernelGGL((k_crestore<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.w, g.ctile, g.ch.cstale,
+                                          g.ch.stale_list, g.ch.stale_count));
+        (void)hipMemsetAsync(g.ch.stale_count, 0, sizeof(int), st);
+      });
+    });
   // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
   for (int it = 0; it < K; ++it) {
     ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, it == 0 ? g.ch.p : g.ch.PM); });
@@ -807,7 +823,7 @@ Chains chains_view(const rmhmc_ctx* ctx, long long off, int n) {
     r->ljl += off; r->hld += off;
   }
   v.p = vec(v.p); v.p0 = vec(v.p0); v.Hcur += off; v.Hprop += off; v.tau += off;
-  v.steps_left += off; v.phase += off; v.status += off; v.nsteps_last += off; v.cstale += off;
+  v.steps_left += off; v.phase += off; v.status += off; v.nsteps_last += off; v.cstale += off; v.stale_list += off;
   v.iter += off; v.accepted += off; v.steps_done += off;
   v.wq = vec(v.wq); v.uq = vec(v.uq); v.PM = vec(v.PM); v.u0 = vec(v.u0); v.q = vec(v.q); v.last = vec(v.last);
   v.Gq = mat(v.Gq); v.rv0 += off * Mp; v.rv2 += off * Mp;
@@ -855,6 +871,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
   ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
   if (const char* e = getenv("RMHMC_CCACHE")) ctx->ccache = atoi(e) != 0;
   if (const char* e = getenv("RMHMC_CDYN")) ctx->cdyn = atoi(e) != 0;
+  if (const char* e = getenv("RMHMC_CRESTORE")) ctx->crestore = atoi(e) != 0;
   if (const char* e = getenv("RMHMC_I8_TAIL")) ctx->i8_tail = atoi(e) ? 1 : 0;
   if (const char* e = getenv("RMHMC_I8_DELTA")) ctx->i8_delta = atoi(e) ? 1 : 0;
   if (const char* e = getenv("RMHMC_I8_DELTA_INNER")) ctx->i8_delta_inner = atoi(e) ? 1 : 0;
@@ -878,6 +895,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     }
     RC(dalloc(ctx, &ch.p, n * DP)); RC(dalloc(ctx, &ch.p0, n * DP)); RC(dalloc(ctx, &ch.Hcur, n)); RC(dalloc(ctx, &ch.Hprop, n));
     RC(dalloc(ctx, &ch.tau, n)); RC(dalloc(ctx, &ch.steps_left, n)); RC(dalloc(ctx, &ch.phase, n)); RC(dalloc(ctx, &ch.status, n)); RC(dalloc(ctx, &ch.cstale, n));
+    RC(dalloc(ctx, &ch.stale_list, n)); RC(dalloc(ctx, &ch.stale_count, (size_t)16));  // (one counter per group)
     RC(dalloc(ctx, &ch.nsteps_last, n)); RC(dalloc(ctx, &ch.iter, n)); RC(dalloc(ctx, &ch.accepted, n)); RC(dalloc(ctx, &ch.steps_done, n));
     RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
     RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
@@ -1078,6 +1096,16 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     snprintf(g_err, 512, "%s", ctx->err);
     rmhmc_destroy(ctx);
     return rc;
+  }
+  {  // list of the chains that have just rejected a proposal (k_crestore): generic multi-launch path with c tiles only
+    int gi = 0;
+    for (Group& g : ctx->groups) {
+      const bool ok = !ctx->big && !ctx->medium && !ctx->fused && g.ctile && ctx->cdyn && ctx->crestore && gi < 16;
+      g.ch.stale_count = ctx->ch.stale_count + std::min(gi, 15);
+      if (!ok) g.ch.stale_list = nullptr;
+      ++gi;
+    }
+    ctx->ch.stale_list = nullptr;
   }
   *out = ctx;
   return RMHMC_OK;
