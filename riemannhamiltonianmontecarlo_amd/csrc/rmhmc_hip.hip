@@ -582,7 +582,11 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     ph.push_back([=](Group& g) {
       if (!g.ctile || !g.ch.stale_list) return;
       launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
-        const int rsplit = std::max(1, std::min(64, ctx->Mp / 32 / 4));  // (row pieces of this kernel's own: few wavefronts, short pieces)
+        // row pieces of this kernel's own.  Measured at config 3 (~300 chains = 19 wavefront groups per step): 16 pieces 86 us, 64 pieces 94,
+        // 314 pieces (one block per wavefront) 149 - a wavefront alone on its SIMD takes ~4.3 us per 32-row block (load - product - exp
+        // latencies with nothing to hide them), and every workgroup that only reads the count and returns costs ~15-30 ns.
+        int rsplit = std::max(1, std::min(16, ctx->Mp / 32 / 4));
+        if (const char* e = getenv("RMHMC_CRESTORE_SPLIT")) rsplit = std::max(1, atoi(e));
         // (room for 2048 rejected chains; any beyond stay flagged and k_mompass<.., 3> recomputes their wavefronts as before.  A grid for
         //  the whole batch spent 100 us launching 8192 workgroups of which ~5 % had work.)
         dim3 grid((unsigned)std::min((g.n + 63) / 64, 32), (unsigned)rsplit);
