@@ -39,8 +39,11 @@ def hip():
     return _capi.load_hip_library()
 
 
+# (the last two: the blocked large-D path, 64 < D <= 256 - three column blocks with a ragged M, and BASELINE config 5's own shape, whose
+#  tape holds vectors, scalars and matrix DIAGONALS only: tests/golden/make_golden.py large_d_tapes)
 TAPES = ["pima", "australian", "german", "heart", "ripley", "syn_m1000_d8", "syn_m50_d5_L1", "syn_m300_d20", "syn_m203_d33",
-         "syn_m10000_d64_L1", "guard_w"]
+         "syn_m10000_d64_L1", "guard_w", "syn_m3001_d130", "syn_m50000_d256_L1"]
+LITERAL_TOO_SLOW = ("syn_m10000_d64_L1", "syn_m3001_d130", "syn_m50000_d256_L1")  # O(M D^3) tensor in scalar C: minutes
 
 
 def load_tape(name):
@@ -59,3 +62,22 @@ def load_tape(name):
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def mat_err(G, g, key):
+    """rel_err of a D x D matrix against the tape's copy, or of its diagonal when the tape is a compact one (``diag`` + key)."""
+    for cut in range(len(key), 0, -1):                       # "it0_s0_G_end" -> "it0_s0_" + "diag" + "G_end"
+        if key[:cut].endswith("_") and (key[:cut] + "diag" + key[cut:]) in g:
+            return rel_err(np.diag(np.asarray(G)), g[key[:cut] + "diag" + key[cut:]])
+    return rel_err(G, g[key])
+
+
+def logdet_after_first_step(g):
+    """log|G| at the end of the first leapfrog step of transition 0, from the reference's own values: slogdet of its G where the tape
+    holds the matrix; for a compact tape (one-step trajectories) 2 x ProposedLogDet (rmhmc.py:171)."""
+    if "it0_s0_G_end" in g:
+        sign, ld = np.linalg.slogdet(g["it0_s0_G_end"])
+        assert sign > 0
+        return float(ld)
+    assert int(g["nsteps"][0]) == 1
+    return 2.0 * float(g["hld_prop"][0])

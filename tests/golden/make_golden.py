@@ -9,7 +9,7 @@ that the oracle (oracle/rmhmc_oracle.c) and the HIP library can replay exactly
 the same transitions.  Output: small ``.npz`` files next to this script.
 
     python tests/golden/make_golden.py            # regenerate everything
-    python tests/golden/make_golden.py ripley loader ess4096     # only the named groups (base, ripley, loader, ess4096)
+    python tests/golden/make_golden.py ripley loader ess4096     # only the named groups (base, ripley, loader, ess4096, larged)
 
 The fixtures hold data only (inputs, random draws, expected outputs); no
 reference source text is stored.
@@ -58,8 +58,11 @@ def _check_lines():
 class Recorder:
     """Per-transition record of the reference's state."""
 
-    def __init__(self, detail_iters):
+    def __init__(self, detail_iters, compact=False):
         self.detail_iters = detail_iters
+        # compact: D x D matrices are reduced to their diagonals when recorded (the large-D tapes: five 512 KB matrices
+        # per step would be most of the fixture directory; vectors, scalars and diag(G) pin the same code paths)
+        self.mat = (lambda A: np.diag(A).copy()) if compact else (lambda A: A.copy())
         self.iters = []  # one dict per IterationNum
         self.cur = None
         self.draws = []  # (kind, value) in call order
@@ -89,15 +92,15 @@ class Recorder:
                 c["nsteps"] = int(L["RandomStep"])
                 c["dir"] = int(L["TimeStep"])
                 if detail:
-                    c["G0"] = L["G"].copy()
-                    c["InvG0"] = L["InvG"].copy()
+                    c["G0"] = self.mat(L["G"])
+                    c["InvG0"] = self.mat(L["InvG"])
                     c["tr0"] = L["TraceInvGdG"].copy().ravel()
-                    c["cholG0"] = L["OriginalCholG"].copy()
+                    c["cholG0"] = self.mat(L["OriginalCholG"])
             elif detail:
                 st = c["steps"][-1]
                 st["w_end"] = L["wNew"].copy().ravel()
                 st["p_end"] = L["ProposedMomentum"].copy().ravel()
-                st["G_end"] = L["G"].copy()
+                st["G_end"] = self.mat(L["G"])
                 st["tr_end"] = L["TraceInvGdG"].copy().ravel()
                 st["grad_end"] = L["likelihood_grad"].copy().ravel()
             c["seen96"] += 1
@@ -111,12 +114,12 @@ class Recorder:
             c["w_prop"] = L["wNew"].copy().ravel()
             c["p_prop"] = L["ProposedMomentum"].copy().ravel()
             if detail:
-                c["G_prop"] = L["G"].copy()
+                c["G_prop"] = self.mat(L["G"])
                 if c["steps"]:
                     st = c["steps"][-1]
                     st["w_end"] = c["w_prop"]
                     st["p_end"] = c["p_prop"]
-                    st["G_end"] = L["G"].copy()
+                    st["G_end"] = self.mat(L["G"])
                     st["tr_end"] = L["TraceInvGdG"].copy().ravel()
                     st["grad_end"] = L["likelihood_grad"].copy().ravel()
         elif ln == 179:
@@ -153,9 +156,10 @@ def recording_rng(rec):
         np.random.randn, np.random.rand = o_randn, o_rand
 
 
-def capture(XX, t, seed, n_iter, L=6, eps=0.5, K=4, detail_iters=2):
-    """Run the reference for n_iter transitions and return a flat dict of arrays."""
-    rec = Recorder(detail_iters)
+def capture(XX, t, seed, n_iter, L=6, eps=0.5, K=4, detail_iters=2, compact=False):
+    """Run the reference for n_iter transitions and return a flat dict of arrays.  compact=True stores diag(G) etc. under
+    the keys ``*diagG0`` / ``*diagG_end`` ... instead of the full matrices."""
+    rec = Recorder(detail_iters, compact)
     np.random.seed(seed)
     buf = io.StringIO()
     with recording_rng(rec), contextlib.redirect_stdout(buf), np.errstate(all="ignore"):
@@ -206,8 +210,10 @@ def capture(XX, t, seed, n_iter, L=6, eps=0.5, K=4, detail_iters=2):
     for it in range(min(detail_iters, T)):
         c = rec.iters[it]
         pre = "it%d_" % it
-        out[pre + "G0"] = c["G0"]; out[pre + "InvG0"] = c["InvG0"]; out[pre + "tr0"] = c["tr0"]; out[pre + "cholG0"] = c["cholG0"]
-        out[pre + "G_prop"] = c["G_prop"]
+        m = "diag" if compact else ""
+        out[pre + m + "G0"] = c["G0"]; out[pre + m + "InvG0"] = c["InvG0"]; out[pre + "tr0"] = c["tr0"]
+        out[pre + m + "cholG0"] = c["cholG0"]
+        out[pre + m + "G_prop"] = c["G_prop"]
         assert len(c["steps"]) == c["nsteps"]
         for s, st in enumerate(c["steps"]):
             sp = pre + "s%d_" % s
@@ -216,7 +222,7 @@ def capture(XX, t, seed, n_iter, L=6, eps=0.5, K=4, detail_iters=2):
             out[sp + "grad_start"] = st["grad_start"]
             out[sp + "PM"] = np.stack(PM)   # PM[0] = p at step start, PM[k] after k fixed-point iterations
             out[sp + "Pw"] = np.stack(Pw)   # Pw[0] = w at step start, Pw[k] after k iterations
-            out[sp + "w_end"] = st["w_end"]; out[sp + "p_end"] = st["p_end"]; out[sp + "G_end"] = st["G_end"]
+            out[sp + "w_end"] = st["w_end"]; out[sp + "p_end"] = st["p_end"]; out[sp + m + "G_end"] = st["G_end"]
             out[sp + "tr_end"] = st["tr_end"]; out[sp + "grad_end"] = st["grad_end"]
     return out
 
@@ -273,9 +279,28 @@ def ess_4096_fixture():
     save("ess_s4096", samples=x.astype(np.float64), ess=ess.ravel(), acf64=acf, maxlag=np.int64(S - 1))
 
 
+def large_d_tapes():
+    """64 < D <= 256: the blocked (tiled-Cholesky) path of the build, pinned to rmhmc.py:96-175 itself.  D = 130 with the
+    matrices of the first transition in full (three column blocks, ragged M); BASELINE config 5's own shape (M = 50000,
+    D = 256: the reference forms its 134 MB InvGdG tensor twice, about a minute here) for exactly one leapfrog step with
+    vectors, scalars and diagonals only."""
+    for name, M, D, dseed, seed, n_iter, L, compact in (
+            ("syn_m3001_d130", 3001, 130, 4, 10, 3, 2, False),
+            ("syn_m50000_d256_L1", 50000, 256, 0, 11, 1, 1, True)):
+        XX, t = synthetic_logreg(M, D, dseed)
+        g = capture(XX, t, seed, n_iter, L=L, detail_iters=1, compact=compact)
+        if not compact:      # keep G0 and the per-step G_end of the detailed transition, drop the three other D x D copies
+            for k in ("it0_InvG0", "it0_cholG0", "it0_G_prop"):
+                g.pop(k)
+        g.update(M=np.int64(M), D=np.int64(D), data_seed=np.int64(dseed))
+        save("tape_" + name, **g)
+
+
 def main():
     _check_lines()
-    groups = set(sys.argv[1:]) or {"base", "ripley", "loader", "ess4096"}
+    groups = set(sys.argv[1:]) or {"base", "ripley", "loader", "ess4096", "larged"}
+    if "larged" in groups:
+        large_d_tapes()
     if "ripley" in groups:
         ripley_tape()
     if "loader" in groups:
