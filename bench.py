@@ -134,7 +134,19 @@ def main():
                          "stationarity (the metric's window is the post-burn-in sampling phase, rmhmc.py:194-198).  Default: 300 for the "
                          "large batched workloads (about 85 transitions; 80 at D > 64), 0 otherwise; alternates.cold_start times the first steps from theta0")
     ap.add_argument("--no-fp64-roofline", action="store_true", help="skip the extra fp64-matrix-core run behind roofline_fp64")
+    ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay (library option graph = 0)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="a tuning option of include/rmhmc.h (rmhmc_create_opts / rmhmc_set_option), repeatable; the active set is reported in config.options")
+    ap.add_argument("--save-state", default="", help="after the burn-in steps, write the chain state (rmhmc_chains_state: a complete checkpoint) to this .npz and exit")
+    ap.add_argument("--load-state", default="", help="start from a checkpoint written by --save-state instead of running the burn-in steps (bit-exact "
+                    "resume, rmhmc_chains_restore): lets a profiler see stationary steps only (tools/profile.sh)")
     args = ap.parse_args()
+    opts = {}
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        opts[k] = int(v)
+    if args.no_graph:
+        opts["graph"] = 0
 
     import torch
     import torch.distributed as dist
@@ -174,17 +186,35 @@ def main():
         gpu_flags |= _capi.FLAG_INT8_CERTIFY   # as the shims do: rmhmc_set_data checks the fixed-point error bound for this data
 
     lib = _capi.load_hip_library()  # raises if the extension is not built
-    ctx = lib.context(M, D, n, flags=gpu_flags, device=dev)
-    ctx.set_data(XX, t)
+
+    def make_context(fl):
+        """(rmhmc_create_opts takes every key; the run-time ones could also be changed later with rmhmc_set_option)"""
+        c = lib.context(M, D, n, flags=fl, device=dev, options=opts or None)
+        c.set_data(XX, t)
+        return c
+
+    ctx = make_context(gpu_flags)
+    active_options = ctx.options()
     i8_bound, i8_active = ctx.int8_certificate()
     if args.i8_slices and not i8_active:   # not certified to 1e-9: the library runs this data on the fp64 matrix cores
         args.i8_slices = 0
-    ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
     if args.burn_in_steps < 0:
         big_batch = 8 < D <= 256 and n * float(M) * D * D >= 1e9
         args.burn_in_steps = (300 if D <= 64 else 80) if big_batch else 0   # (config 5: 0.5 s per global step)
-    if args.burn_in_steps:
-        ctx.chains_run(args.burn_in_steps)   # untimed: from theta0 = 1e-3 (rmhmc.py:27) to stationarity
+    if args.load_state:
+        ck = np.load(args.load_state)
+        assert ck["w"].shape == (n, D) and int(ck["burn_in_steps"]) == args.burn_in_steps, "checkpoint of another run"
+        ctx.chains_init(theta0=ck["w"], seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
+        ctx.chains_restore(ck["iters"], ck["accepted"])
+    else:
+        ctx.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
+        if args.burn_in_steps:
+            ctx.chains_run(args.burn_in_steps)   # untimed: from theta0 = 1e-3 (rmhmc.py:27) to stationarity
+    if args.save_state:
+        w_ck, it_ck, acc_ck = ctx.chains_state()
+        np.savez(args.save_state, w=w_ck, iters=it_ck, accepted=acc_ck, burn_in_steps=np.int64(args.burn_in_steps))
+        ctx.close()
+        return
 
     def barrier():
         torch.cuda.synchronize()
@@ -240,19 +270,9 @@ def main():
         # post-burn-in phase (TimeTaken semantics, rmhmc.py:194-198).  ESS by tools.CalculateESS semantics with
         # the MATLAB FFT length (no wrap-around); estimated on a subset of chains to bound the host FFT work.
         burn = 100
-        # Under rocprofv3 the sampler's phase schedule (graph replays of the whole batch followed by direct launches of its prefixes)
-        # makes librocprofiler-sdk 7.2 fault in its dispatch-completion callback once the step holds the two-wave tail tiles (backtrace:
-        # hsa-runtime async handler -> librocprofiler-sdk.so; any one of RMHMC_GRAPH=0 / RMHMC_SORTED=0 / RMHMC_I8_TAIL=0 avoids it,
-        # and nothing happens without the profiler).  A profiled run therefore takes this leg without graph replay.
-        profiled = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
-        graph_off = profiled and "RMHMC_GRAPH" not in os.environ
-        if graph_off:
-            os.environ["RMHMC_GRAPH"] = "0"
         st = ctx.sample_stats_dev(torch.device("cuda", dev), burn + args.ess_iters, burn, L=L, eps=eps, K=K, seed=7, chain_offset=rank * n)
-        if graph_off:
-            del os.environ["RMHMC_GRAPH"]
-        me = torch.nan_to_num(st["ess"], nan=float("inf")).amin(dim=1)        # per chain: min over dimensions
-        me = me[torch.isfinite(me)]
+        me = torch.nan_to_num(st["ess"], nan=float("inf")).amin(dim=1)        # per chain: min over dimensions (NaN: a constant coordinate)
+        me = me[torch.isfinite(me)]                                            # (a chain with no finite ESS at all counts for nothing)
         tot = float(me.sum()); secs = st["seconds"]; lsteps = float(st["leapfrog_steps"].sum()); acc_n = float(st["accepted"].sum())
         if world > 1:
             tt = torch.tensor([tot, lsteps, acc_n], device=ddev, dtype=torch.float64); dist.all_reduce(tt)
@@ -262,7 +282,7 @@ def main():
                "post_burn_in_transitions": args.ess_iters, "burn_in": burn, "compat": bool(args.compat),
                "mean_min_ess_per_chain": tot / (n * world), "chains": n * world,
                "leapfrog_steps_per_sec_during_sampling": lsteps / secs,
-               "acceptance": acc_n / float((burn + args.ess_iters) * n * world), "graph_replay": not graph_off,
+               "acceptance": acc_n / float((burn + args.ess_iters) * n * world), "graph_replay": bool(active_options.get("graph", 1)),
                "note": "per-chain ESS (MATLAB CalculateStatistics.m semantics: ESS per chain, min over dimensions; tools.py:32-74 "
                        "estimator with linear autocovariances = the MATLAB FFT length, no wrap-around), summed over all chains; seconds = "
                        "the post-burn-in window of rmhmc.py:194-198; computed on the device by rmhmc_sample_stats_dev (no sample transfer)"}
@@ -365,7 +385,8 @@ def main():
         out = {
             "metric": "leapfrog-steps/sec (whole node)", "value": value, "unit": "leapfrog-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 (the two O(M D^2) contractions as exact int8-sliced integer GEMMs)" if args.i8_slices else "f64",
             "dtype_detail": ("f64 throughout; the two O(M D^2) contractions (metric assembly, leverages) as exact integer GEMMs: operands cut into %d "
                              "signed-byte slices, int8 MFMA with int32 accumulation, combined in f64 (G to ~2e-14 of the f64 oracle at 6 slices)%s"
                              % (args.i8_slices, "; the metric of the position fixed-point iterates before the last (it only steers the next iterate) "
@@ -375,7 +396,7 @@ def main():
             "data": "synthetic" if args.workload != "c1" else "bundled australian.csv",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "chains_per_gpu": n, "chains_total": n * world,
                        "D": D, "M": M, "leapfrog_L": L, "step_size": eps, "fixed_point_K": K,
-                       "compat": bool(args.compat),
+                       "compat": bool(args.compat), "options": active_options,
                        "chain_state": ("stationary: %d untimed global steps from theta0 before the warmup (the metric's window is the post-burn-in "
                                        "sampling phase, rmhmc.py:194-198); alternates.cold_start = the first steps from theta0" % args.burn_in_steps)
                        if args.burn_in_steps else "first steps from theta0 = 1e-3 (rmhmc.py:27)",
@@ -401,8 +422,7 @@ def main():
         big = 8 < D <= 256 and n * float(M) * D * D >= 1e9
 
         def run_variant(sl, steps, timing, extra=0, burn=None):
-            c2 = lib.context(M, D, n, flags=flags | extra | (_capi.int8_metric_flags(sl) if sl else 0), device=dev)
-            c2.set_data(XX, t)
+            c2 = make_context(flags | extra | (_capi.int8_metric_flags(sl) if sl else 0))
             c2.chains_init(seed=2024, chain_offset=rank * n, L=L, eps=eps, K=K)
             burn = args.burn_in_steps if burn is None else burn
             if burn:

@@ -104,6 +104,39 @@ const char *rmhmc_version(void);
  * usable (there is no CPU fallback in the product library). */
 int rmhmc_create(rmhmc_ctx **out, int32_t device_id, int64_t M, int32_t D,
                  int64_t n_chains, int32_t dtype, uint32_t flags);
+
+/* Tuning options: every switch of the HIP library that changes its schedule or the last bits of its results, as explicit
+ * arguments (the library reads NO environment variables).  rmhmc_create is rmhmc_create_opts with no options.  Keys marked
+ * [create] shape allocations or the choice of kernels and can only be given to rmhmc_create_opts; the others may also be changed
+ * later with rmhmc_set_option (between calls: the context is not thread-safe).  rmhmc_options writes the active set as
+ * "key=value key=value ..." (rmhmc_device_info appends it too).  Unknown key / value out of range: RMHMC_ERR_INVALID.
+ *
+ *   key               default  meaning
+ *   graph             1        replay the launches of one global step from a hipGraph (0: plain launches)
+ *   sorted            1        bulk samplers lay the chains out by decreasing post-burn-in work and shrink the launches of
+ *                              the tail to the chains still running (results bit-identical either way)
+ *   inflight          32       at most this many global steps (or graph replays) queued on the device ahead of the host
+ *                              (0: unbounded)
+ *   cdyn              1        first momentum pass of a step re-uses the c = v(1-2p) tiles of chains that did not just reject
+ *   crestore          1        ... and the tiles of the chains that did are recomputed for them alone (k_crestore)
+ *   i8_force_rebase   0        test hook: delta assemblies treat every chain as if its fixed-point exponent had changed
+ *   ccache   [create] 1        c tiles kept per position for the momentum passes (0: recomputed by every pass)
+ *   medium   [create] 1        one-launch leapfrog step / HMC trajectory for small batches (8 < D <= 32, M <= 2048, <= 512 chains)
+ *   fused    [create] 1        LDS-resident many-steps-per-launch kernel for D <= 8
+ *   hmc_traj_maxn [create] -1  largest batch for the one-launch HMC trajectory (-1: the built-in rule)
+ *   fsplit   [create] 0        row ranges per chain of the fp64 assembly of small batches (0: chosen from the batch size)
+ *   nsplit_max [create] 64     cap on the row splits of the 16-chains-per-wavefront passes
+ *   i8_tail  [create] -1       int8 path: ragged last pair block as tiles of its own: -1 when it pays, 0 never, 1 always
+ *   i8_delta [create] 1        int8 path, 6 slices: the metric at the end of a leapfrog step as G(last iterate) + the assembly
+ *                              of the v differences (4 slices)
+ *   i8_delta_inner [create] 1  ... and the second position iterate from the first likewise
+ * The CPU oracle accepts every key and ignores the values. */
+typedef struct { const char *key; int64_t value; } rmhmc_option;
+int rmhmc_create_opts(rmhmc_ctx **out, int32_t device_id, int64_t M, int32_t D, int64_t n_chains, int32_t dtype,
+                      uint32_t flags, const rmhmc_option *opts, int32_t n_opts);
+int rmhmc_set_option(rmhmc_ctx *ctx, const char *key, int64_t value);
+int rmhmc_get_option(rmhmc_ctx *ctx, const char *key, int64_t *value_out);
+int rmhmc_options(rmhmc_ctx *ctx, char *buf, size_t len);
 void rmhmc_destroy(rmhmc_ctx *ctx);
 const char *rmhmc_last_error(const rmhmc_ctx *ctx);
 /* Human-readable device / build description into buf (NUL-terminated). */
@@ -250,6 +283,9 @@ int rmhmc_sample_stats(rmhmc_ctx *ctx, int64_t n_iter, int64_t burn_in, int32_t 
  *   Several chains: nobody is stopped; the report for m comes at the first host synchronisation after the SLOWEST chain has
  *   completed m transitions (the others are ahead, iterations > n m), and milestones passed since the last report are merged
  *   into one call with the largest of them.
+ * A milestone equal to burn_in+1 falls where the reference prints it: rmhmc_sample* after the burn-in event (rmhmc.py:38 prints at the
+ * top of the next iteration), rmhmc_hmc_sample before it (hmc.py:85-89 prints at the bottom of the iteration); rmhmc_hmc_sample
+ * reports no milestone beyond burn_in+1 (hmc.py:83-89 prints during burn-in only), so nothing cuts its TimeTaken window.
  * fn(RMHMC_EV_BURNIN_DONE, burn_in+1, accepted, iterations, user) is called when the burn-in phase ends (every chain at exactly
  * burn_in+1 transitions), just before the TimeTaken timer starts.  Samples do not depend on any of it.  fn = NULL switches the
  * reports off.  The oracle accepts the call and never reports.                                                            */

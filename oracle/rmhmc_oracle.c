@@ -1169,3 +1169,25 @@ int rmhmc_set_progress(rmhmc_ctx *ctx, rmhmc_progress_fn fn, int64_t first, int6
   (void)fn; (void)first; (void)every; (void)user;   /* the oracle runs its chains to the end in parallel loops and never reports */
   return ctx ? RMHMC_OK : RMHMC_ERR_INVALID;
 }
+
+/* Tuning options of the HIP library (include/rmhmc.h): scheduling switches that have no meaning for the serial restatement.  Accepted
+ * and ignored, so that a test can hand both libraries the same option set. */
+int rmhmc_create_opts(rmhmc_ctx **out, int32_t device_id, int64_t M, int32_t D, int64_t n_chains, int32_t dtype, uint32_t flags,
+                      const rmhmc_option *opts, int32_t n_opts) {
+  if (n_opts < 0 || (n_opts > 0 && !opts)) return fail(NULL, RMHMC_ERR_INVALID, "create_opts: bad option array");
+  return rmhmc_create(out, device_id, M, D, n_chains, dtype, flags);
+}
+int rmhmc_set_option(rmhmc_ctx *ctx, const char *key, int64_t value) {
+  (void)value;
+  return (ctx && key) ? RMHMC_OK : RMHMC_ERR_INVALID;
+}
+int rmhmc_get_option(rmhmc_ctx *ctx, const char *key, int64_t *value_out) {
+  if (!ctx || !key || !value_out) return RMHMC_ERR_INVALID;
+  *value_out = 0;
+  return RMHMC_OK;
+}
+int rmhmc_options(rmhmc_ctx *ctx, char *buf, size_t len) {
+  if (!ctx || !buf || !len) return RMHMC_ERR_INVALID;
+  buf[0] = 0;
+  return RMHMC_OK;
+}

@@ -58,8 +58,20 @@ _lp = C.POINTER(C.c_int64)
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
 EV_PROGRESS, EV_BURNIN_DONE = 0, 1
 
+
+
+class Option(C.Structure):
+    """rmhmc_option of include/rmhmc.h: one (key, value) tuning option"""
+    _fields_ = [("key", C.c_char_p), ("value", C.c_int64)]
+
+
 # every symbol include/rmhmc.h declares, with its signature
 SIGNATURES = {
+    "rmhmc_create_opts": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_uint32,
+                                    C.POINTER(Option), C.c_int32]),
+    "rmhmc_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "rmhmc_get_option": (C.c_int, [C.c_void_p, C.c_char_p, _lp]),
+    "rmhmc_options": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "rmhmc_version": (C.c_char_p, []),
     "rmhmc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_uint32]),
     "rmhmc_destroy": (None, [C.c_void_p]),
@@ -126,22 +138,29 @@ class RmhmcLib:
             fn = getattr(self.lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
+        # the HIP library writes its _dev outputs through device pointers of its own GPU; the CPU oracle's "device" is the host
+        self.on_gpu = "gfx950" in self.version()
 
     def version(self):
         return self.lib.rmhmc_version().decode()
 
-    def context(self, M, D, n_chains=1, flags=COMPAT, device=0):
-        return Context(self, M, D, n_chains, flags, device)
+    def context(self, M, D, n_chains=1, flags=COMPAT, device=0, options=None):
+        """options: dict of the tuning options of include/rmhmc.h (rmhmc_create_opts), e.g. {"graph": 0, "medium": 0}"""
+        return Context(self, M, D, n_chains, flags, device, options)
 
 
 class Context:
     """One opaque rmhmc_ctx: M data rows, D dims, n_chains chains on one device."""
 
-    def __init__(self, rl, M, D, n_chains, flags, device):
+    def __init__(self, rl, M, D, n_chains, flags, device, options=None):
         self.rl, self.lib = rl, rl.lib
         self.M, self.D, self.n, self.flags = int(M), int(D), int(n_chains), int(flags)
         self._h = C.c_void_p()
-        rc = self.lib.rmhmc_create(C.byref(self._h), device, self.M, self.D, self.n, F64, self.flags)
+        if options:
+            arr = (Option * len(options))(*[Option(str(k).encode(), int(v)) for k, v in options.items()])
+            rc = self.lib.rmhmc_create_opts(C.byref(self._h), device, self.M, self.D, self.n, F64, self.flags, arr, len(options))
+        else:
+            rc = self.lib.rmhmc_create(C.byref(self._h), device, self.M, self.D, self.n, F64, self.flags)
         if rc != 0:
             raise RmhmcError(rc, self.lib.rmhmc_last_error(None).decode())
 
@@ -167,9 +186,24 @@ class Context:
             raise RmhmcError(rc, self.lib.rmhmc_last_error(self._h).decode())
 
     def device_info(self):
-        buf = C.create_string_buffer(512)
-        self._ck(self.lib.rmhmc_device_info(self._h, buf, 512))
+        buf = C.create_string_buffer(1024)
+        self._ck(self.lib.rmhmc_device_info(self._h, buf, 1024))
         return buf.value.decode()
+
+    def set_option(self, key, value):
+        """a run-time tuning option (include/rmhmc.h); create-time ones go to ``context(..., options={...})``"""
+        self._ck(self.lib.rmhmc_set_option(self._h, str(key).encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._ck(self.lib.rmhmc_get_option(self._h, str(key).encode(), C.cast(C.byref(v), _lp)))
+        return v.value
+
+    def options(self):
+        """the active option set as a dict (empty for the CPU oracle)"""
+        buf = C.create_string_buffer(1024)
+        self._ck(self.lib.rmhmc_options(self._h, buf, 1024))
+        return {k: int(v) for k, v in (kv.split("=") for kv in buf.value.decode().split())}
 
     def set_data(self, XX, t, alpha=100.0):
         XX = _f64(XX)

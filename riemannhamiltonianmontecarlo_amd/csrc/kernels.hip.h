@@ -62,7 +62,6 @@ struct Chains {
   // scratch
   double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv2, *ljl_part, *qpart, *gpart;
   int n;
-  int hiprio;  // light kernels raise their wave priority when they co-run with another group's MFMA kernel
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1197,7 +1196,6 @@ __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict
 __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps) {
   __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   load_mat_lds<true>(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
   const double rdiag = (lane < D) ? 1.0 / A[rm_row<true>(lane) + lane] : 1.0;
@@ -1214,7 +1212,6 @@ template <int NB>
 __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, double eps) {
   __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   load_mat_lds<true>(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
   double rdiag;
@@ -1235,7 +1232,6 @@ __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, d
 // accept the position iterate as the new w and apply the position guard (rmhmc.py:123-130)
 __global__ __launch_bounds__(64) void k_pos_final(int D, int DP, Chains ch, int guards) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   const size_t o = (size_t)c * DP;
   double ss = 0.0;
@@ -1367,7 +1363,6 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int n
   constexpr int DPc = 16 * NB;
   const int D = dd.D, DP = dd.DP;
   const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   load_mat_lds<true>(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
   double rdiag;
@@ -1411,7 +1406,6 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int n
 // u = G^-1 v for the momentum fixed point (rmhmc.py:104); src = p (first iterate) or PM
 __global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, const double* __restrict__ src) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
   double u[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
@@ -1431,7 +1425,6 @@ __global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, co
 // PM = p + tau*eps/2 * (grad - tr/2 + q/2)   (rmhmc.py:108); final != 0: p = PM (rmhmc.py:110)
 __global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, double eps, int final, int nsplit) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   const double h = ch.tau[c] * eps * 0.5;
   for (int d = lane; d < D; d += 64) {
@@ -1447,7 +1440,6 @@ __global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, dou
 // explicit momentum half step at the new point (rmhmc.py:163) + step bookkeeping
 __global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, double eps, int advance, int nsplit) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   if (ch.phase[c] != 1) return;
   const double h = ch.tau[c] * eps * 0.5;
   int nonfinite = 0;
@@ -1634,7 +1626,6 @@ __device__ __forceinline__ void iter_begin_dev(int D, int DP, const Chains& ch, 
 __global__ __launch_bounds__(64) void k_iter_begin(int D, int DP, Chains ch, IterParams ip) {
   __shared__ double zs[RM_DMAX];
   __shared__ double ps[RM_DMAX];
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   iter_begin_dev(D, DP, ch, ip, blockIdx.x, threadIdx.x, zs, ps);
 }
 
@@ -1677,7 +1668,6 @@ __device__ __forceinline__ void iter_end_dev(int D, int DP, const Chains& ch, co
 
 __global__ __launch_bounds__(64) void k_iter_end(int D, int DP, Chains ch, IterParams ip) {
   __shared__ double ps[RM_DMAX];
-  if (ch.hiprio) __builtin_amdgcn_s_setprio(3);
   iter_end_dev(D, DP, ch, ip, blockIdx.x, threadIdx.x, ps);
 }
 

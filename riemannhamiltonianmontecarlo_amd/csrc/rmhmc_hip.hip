@@ -32,18 +32,15 @@ constexpr int MAX_LDS = 160 * 1024;
 
 struct EvPair { hipEvent_t a, b; };
 
-// A contiguous range of chains with its own view of the per-chain arrays.  Large batches are split into
-// two groups that are ping-ponged: the heavy matrix-core kernels of both groups run back to back on the
-// main stream while each group's light kernels (Cholesky, vector updates, transition control) run on a
-// side stream under the other group's heavy kernel; per-group events carry the dependencies.
+// The batch of chains a launch works on, with its view of the per-chain arrays and the scratch sized for it.  There is one per context
+// (the whole batch); the work-sorted sampler narrows a copy of it to the prefix of chains still running (launch_global_step_prefix).
+// (Rounds 1-2 could cut the batch into 2-4 groups ping-ponged over two streams; measured twice without gain on MI355X - the co-running
+// light kernels are starved and the heavy ones slow down by the same total, profiles/r01_groups_sweep.txt - and removed.)
 struct Group {
   Chains ch{};
   int n = 0;
   long long off = 0;
   int nsplit = 1;
-  std::vector<hipEvent_t> ring;
-  size_t ring_pos = 0;
-  int prev = -1;  // stream of the group's previous launch: 0 main, 1 side, -1 none since the last fork
   int8_t* Vs = nullptr;  // int8 metric path: slices of v, [S][nks][nCp][32]
   int8_t* Qs = nullptr;  // slices of the doubled G^-1 entries, [S][nkp][nCp][32]
   double* qscale = nullptr;
@@ -60,7 +57,38 @@ struct Group {
   int nCp = 0;
 };
 
-enum Cls { HEAVY = 0, LIGHT = 1 };
+enum Cls { HEAVY = 0, LIGHT = 1 };  // (documentation of a launch's kind: matrix-core pass over all rows / per-chain kernel)
+
+// Tuning options (include/rmhmc.h: rmhmc_create_opts / rmhmc_set_option).  The library reads no environment variables.
+struct Options {
+  int64_t graph = 1, sorted = 1, inflight = 32, cdyn = 1, crestore = 1, i8_force_rebase = 0;                 // run time
+  int64_t ccache = 1, medium = 1, fused = 1, hmc_traj_maxn = -1, fsplit = 0, nsplit_max = 64, i8_tail = -1,   // create time
+          i8_delta = 1, i8_delta_inner = 1;
+};
+struct OptionDesc { const char* key; int64_t Options::*slot; bool create_only; int64_t lo, hi; };
+const OptionDesc kOptions[] = {
+    {"graph", &Options::graph, false, 0, 1},
+    {"sorted", &Options::sorted, false, 0, 1},
+    {"inflight", &Options::inflight, false, 0, 1 << 20},
+    {"cdyn", &Options::cdyn, false, 0, 1},
+    {"crestore", &Options::crestore, false, 0, 1},
+    {"i8_force_rebase", &Options::i8_force_rebase, false, 0, 1},
+    {"ccache", &Options::ccache, true, 0, 1},
+    {"medium", &Options::medium, true, 0, 1},
+    {"fused", &Options::fused, true, 0, 1},
+    {"hmc_traj_maxn", &Options::hmc_traj_maxn, true, -1, (int64_t)1 << 40},
+    {"fsplit", &Options::fsplit, true, 0, 64},
+    {"nsplit_max", &Options::nsplit_max, true, 1, 1 << 20},
+    {"i8_tail", &Options::i8_tail, true, -1, 1},
+    {"i8_delta", &Options::i8_delta, true, 0, 1},
+    {"i8_delta_inner", &Options::i8_delta_inner, true, 0, 1},
+};
+const OptionDesc* find_option(const char* key) {
+  if (!key) return nullptr;
+  for (const OptionDesc& d : kOptions)
+    if (!strcmp(d.key, key)) return &d;
+  return nullptr;
+}
 
 }  // namespace
 
@@ -70,8 +98,11 @@ struct rmhmc_ctx {
   int D = 0, DP = 0, NB = 0, Mp = 0, nblk = 0;
   uint32_t flags = 0;
   double alpha = 100.0;
-  hipStream_t stream = nullptr, side = nullptr;
-  hipEvent_t fj_event = nullptr;
+  hipStream_t stream = nullptr;
+  Options opt{};
+  std::vector<hipEvent_t> flow;  // flow control (option inflight): events recorded every few global steps, see flow_tick
+  long long flow_steps = 0, flow_ticks = 0;
+  int* stale_list_alloc = nullptr;  // list of the chains that have just rejected a proposal (k_crestore; in use when cdyn and crestore are on)
   DevData dd{};
   Chains ch{};  // whole-batch view (uploads / downloads)
   std::vector<Group> groups;
@@ -86,18 +117,16 @@ struct rmhmc_ctx {
   size_t fused_lds = 0;
   bool medium = false;       // one-launch leapfrog step for small batches with 8 < D <= 32 (medium_step.hip.h)
   size_t medium_lds = 0;
-  bool crestore = true;      // c tiles of the chains that have just rejected recomputed by k_crestore, 16 to a wavefront (RMHMC_CRESTORE=0: k_mompass<.., 3> alone)
-  bool cdyn = true;          // first momentum pass of a step re-uses the c tiles of chains that did not just reject (RMHMC_CDYN=0: always recomputes)
-  bool ccache = true;        // c = v(1-2p) kept per position in the momentum pass's tile layout (RMHMC_CCACHE=0: recomputed every pass)
+  // (options crestore / cdyn / ccache: c = v(1-2p) kept per position in the momentum pass's tile layout; the first pass of a step re-uses
+  //  the tiles of chains that did not just reject; those of the chains that did are recomputed by k_crestore, 16 to a wavefront)
   bool hmc_traj = false;     // plain HMC in small batches: one launch per trajectory (k_hmc_traj)
   // int8 metric path (metric_i8.hip.h)
   bool i8 = false;
   int i8S = 0, i8_nks = 0, i8_bn = 128, i8_chunk = 1;  // i8_chunk: k-stages (of 32) per launch
-  int i8_inner_drop = 1;     // inner assemblies from S-1 slices (launch_assemble; RMHMC_FLAG_INT8_INNER_FULL / RMHMC_I8_INNER_DROP=0: off)
-  int i8_delta = 1;          // G at the end of a leapfrog step as G(last position iterate) + the assembly of the v differences (RMHMC_I8_DELTA=0: off)
-  int i8_delta_inner = 1;    // the second position iterate likewise, from the first (RMHMC_I8_DELTA_INNER=0: off)
-  int i8_force_rebase = 0;   // (tests: treat every chain as if its v exponent had changed)
-  int i8_tail = -1;          // ragged last pair block as tiles of its own: -1 when it pays (launch_assemble_i8_t), 0 never, 1 always
+  int i8_inner_drop = 1;     // inner assemblies from S-1 slices (launch_assemble; RMHMC_FLAG_INT8_INNER_FULL: off)
+  // (options i8_delta / i8_delta_inner: G at the end of a leapfrog step, and the second position iterate, as the previous iterate's G + the
+  //  assembly of the v differences; i8_force_rebase: tests treat every chain as if its v exponent had changed; i8_tail: ragged last pair
+  //  block as tiles of its own: -1 when it pays (launch_assemble_i8_t), 0 never, 1 always)
   int8_t* d_Zs = nullptr;
   int* d_ze = nullptr;
   int8_t* d_Zt = nullptr;   // leverage pass: x_a x_b sliced per data row, [S][nkp][NRp][32]
@@ -174,38 +203,33 @@ struct Timed {
   ~Timed() { if (on) (void)hipEventRecord(ev.b, st); }
 };
 
-// ---- stream plumbing ------------------------------------------------------------------------------
-// fork: work issued to the side stream from now on is ordered after everything already on the main
-// stream (uploads, fills); join: the main stream waits for the side stream (before downloads).
-void fork_streams(rmhmc_ctx* ctx) {
-  for (Group& g : ctx->groups) g.prev = -1;
-  if (ctx->groups.size() < 2) return;
-  (void)hipEventRecord(ctx->fj_event, ctx->stream);
-  (void)hipStreamWaitEvent(ctx->side, ctx->fj_event, 0);
-}
-void join_streams(rmhmc_ctx* ctx) {
-  if (ctx->groups.size() < 2) return;
-  (void)hipEventRecord(ctx->fj_event, ctx->side);
-  (void)hipStreamWaitEvent(ctx->stream, ctx->fj_event, 0);
-  for (Group& g : ctx->groups) g.prev = -1;
+// Launch one kernel (or a short run of them) on the batch g.  fn(stream) enqueues it; name keys the optional event timing.
+template <typename F>
+void launch(rmhmc_ctx* ctx, Group& g, Cls, const char* name, F&& fn) {
+  (void)g;
+  Timed t(ctx, name, ctx->stream);
+  fn(ctx->stream);
 }
 
-// Launch one kernel of group g.  fn(stream) enqueues it.
-template <typename F>
-void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
-  const bool multi = ctx->groups.size() > 1;
-  const int which = (multi && cls == LIGHT) ? 1 : 0;
-  hipStream_t st = which ? ctx->side : ctx->stream;
-  if (multi && g.prev >= 0 && g.prev != which) (void)hipStreamWaitEvent(st, g.ring[g.ring_pos % g.ring.size()], 0);
-  {
-    Timed t(ctx, name, st);
-    fn(st);
+// Flow control (option inflight): the host is never more than `inflight` global steps ahead of the device.  Every inflight/4 steps an
+// event goes into the stream, and before the host records the fifth it waits for the first.  A run of several hundred steps used to be
+// queued in one go (~45 dispatches per step: tens of thousands of AQL packets), which costs nothing on the bare runtime but is what an
+// intercepting tool's proxy queue cannot take ("Profiler note"); a bounded queue is the better citizen anyway.
+void flow_tick(rmhmc_ctx* ctx, long long steps = 1) {
+  const long long w = ctx->opt.inflight;
+  if (w <= 0) return;
+  ctx->flow_steps += steps;
+  const long long stride = std::max<long long>(1, w / 4);
+  if (ctx->flow_steps < stride) return;
+  ctx->flow_steps = 0;
+  if (ctx->flow.empty()) {
+    ctx->flow.resize(4);
+    for (auto& e : ctx->flow) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   }
-  if (multi) {
-    g.ring_pos++;
-    (void)hipEventRecord(g.ring[g.ring_pos % g.ring.size()], st);
-    g.prev = which;
-  }
+  hipEvent_t e = ctx->flow[ctx->flow_ticks % 4];
+  if (ctx->flow_ticks >= 4) (void)hipEventSynchronize(e);
+  (void)hipEventRecord(e, ctx->stream);
+  ctx->flow_ticks++;
 }
 
 #define NB_SWITCH(ctx, ...)                                               \
@@ -229,12 +253,12 @@ void launch(rmhmc_ctx* ctx, Group& g, Cls cls, const char* name, F&& fn) {
 // the slice planes and its G - summed from all six slices - in Gq, and v moves by 1e-6 between the two points, so the difference
 // needs four slices (10 slice products) where the full assembly needs six (21).
 static bool use_delta(const rmhmc_ctx* ctx, const Group& g) {
-  return ctx->i8 && ctx->i8_delta && (!ctx->big || g.Gbase) && ctx->i8S == 6 && g.ctile && g.ksplit_a <= 1 && ctx->K >= 2 && g.dmax;
+  return ctx->i8 && ctx->opt.i8_delta && (!ctx->big || g.Gbase) && ctx->i8S == 6 && g.ctile && g.ksplit_a <= 1 && ctx->K >= 2 && g.dmax;
 }
 // The second position iterate as a delta of the first (both inner iterates on five slices: it = 2 < K - 1; later inner iterates would need
 // the N of a predecessor whose planes hold differences)
 static bool use_delta_inner(const rmhmc_ctx* ctx, const Group& g, int it) {
-  return use_delta(ctx, g) && ctx->i8_delta_inner && ctx->i8_inner_drop && it == 2 && it < ctx->K - 1;
+  return use_delta(ctx, g) && ctx->opt.i8_delta_inner && ctx->i8_inner_drop && it == 2 && it < ctx->K - 1;
 }
 template <int MODE>
 void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, double* out2 = nullptr, bool delta = false) {
@@ -253,7 +277,7 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
       if (MODE != RP_G && delta) {
         (void)hipMemsetAsync(g.dmax, 0, sizeof(unsigned long long), st);
         VSlice vd = vs;
-        vd.vexp_d = g.vexp_d; vd.rebase = g.rebase; vd.dmax = g.dmax; vd.force_rebase = ctx->i8_force_rebase;
+        vd.vexp_d = g.vexp_d; vd.rebase = g.rebase; vd.dmax = g.dmax; vd.force_rebase = (int)ctx->opt.i8_force_rebase;
         if (MODE == RP_F) {
           NB_SWITCH(ctx, hipLaunchKernelGGL((k_rowpass<NB_, RP_F, 6, false, true>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.phase, w,
                                             out0, nullptr, g.ch.gpart, g.ch.ljl_part, vd, g.ctile, g.ch.cstale));
@@ -291,7 +315,7 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
     if (delta) {  // (large-D path: the planes hold N of the previous iterate, they get the digits of the difference)
       (void)hipMemsetAsync(g.dmax, 0, sizeof(unsigned long long), st);
       hipLaunchKernelGGL((k_vsplit<S, true>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs,
-                         g.vbad, ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp, VDelta{g.vexp_d, g.rebase, g.dmax, ctx->i8_force_rebase});
+                         g.vbad, ctx->D, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp, VDelta{g.vexp_d, g.rebase, g.dmax, (int)ctx->opt.i8_force_rebase});
       return;
     }
     hipLaunchKernelGGL((k_vsplit<S>), dim3((unsigned)((g.n + 7) / 8)), dim3(256), 0, st, v, ctx->Mp, g.n, g.ch.phase, ctx->i8_nks, g.nCp, g.Vs, g.vbad,
@@ -312,7 +336,7 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
   // Ragged last pair block (D = 64: 2080 pairs = 16 blocks of 128 + 32): once the full blocks alone fill the chip, the rest goes to
   // k_assemble_i8_tail (bit-identical results, see there).  RMHMC_I8_TAIL=0 / 1: never / whenever there is a ragged block.
   const int nPBfull = ctx->pairs.NP / (32 * TN * WN);
-  const bool tail = WN == 4 && g.Tq && nPBfull < nPB && (ctx->i8_tail == 1 || (ctx->i8_tail < 0 && (long long)nCB * nPBfull >= 256));
+  const bool tail = WN == 4 && g.Tq && nPBfull < nPB && (ctx->opt.i8_tail == 1 || (ctx->opt.i8_tail < 0 && (long long)nCB * nPBfull >= 256));
   const int npb = tail ? nPBfull : nPB;
   const unsigned nblk_main = (unsigned)(nCB < 8 ? nCB * npb : (nCB + 7) / 8 * 8 * npb);
   const int pb32_0 = nPBfull * TN * WN, ntail = (ctx->pairs.NP - pb32_0 * 32 + 31) / 32;
@@ -423,7 +447,7 @@ void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = fal
 // cmode (generic path): 1 = first pass at this w, c is computed and kept; 2 = c of this w is at hand (k_mompass in kernels.hip.h)
 void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w, int cmode) {
   launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
-    if (!ctx->ccache) cmode = 0;
+    if (!ctx->opt.ccache) cmode = 0;
     if (ctx->big) {
       dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
       switch (cmode) {
@@ -436,7 +460,7 @@ void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w, int cmode) {
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
     switch (cmode) {
       case 1:  // first pass of a step at this w: the tiles are at hand unless the chain has just rejected a proposal (k_mompass<.., 3>)
-        if (ctx->cdyn) { NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 3>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile, g.ch.cstale)); }
+        if (ctx->opt.cdyn) { NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 3>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile, g.ch.cstale)); }
         else { NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 1>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); }
         break;
       case 2: NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass<NB_, 2>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, w, g.ch.uq, g.ch.qpart, g.ctile)); break;
@@ -578,15 +602,14 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
   }
   // c tiles of the chains whose last proposal was rejected (their trj has fallen back to cur): recomputed for them alone, so that the
   // first momentum pass finds every chain's tiles at hand
-  if (!ctx->big && ctx->cdyn)
+  if (!ctx->big && ctx->opt.cdyn)
     ph.push_back([=](Group& g) {
       if (!g.ctile || !g.ch.stale_list) return;
       launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
         // row pieces of this kernel's own.  Measured at config 3 (~300 chains = 19 wavefront groups per step): 16 pieces 86 us, 64 pieces 94,
         // 314 pieces (one block per wavefront) 149 - a wavefront alone on its SIMD takes ~4.3 us per 32-row block (load - product - exp
         // latencies with nothing to hide them), and every workgroup that only reads the count and returns costs ~15-30 ns.
-        int rsplit = std::max(1, std::min(16, ctx->Mp / 32 / 4));
-        if (const char* e = getenv("RMHMC_CRESTORE_SPLIT")) rsplit = std::max(1, atoi(e));
+        const int rsplit = std::max(1, std::min(16, ctx->Mp / 32 / 4));
         // (room for 2048 rejected chains; any beyond stay flagged and k_mompass<.., 3> recomputes their wavefronts as before.  A grid for
         //  the whole batch spent 100 us launching 8192 workgroups of which ~5 % had work.)
         dim3 grid((unsigned)std::min((g.n + 63) / 64, 32), (unsigned)rsplit);
@@ -747,6 +770,7 @@ void launch_fused(rmhmc_ctx* ctx, const IterBase& b, long long nsteps) {
       });
     }
     nsteps -= chunk;
+    flow_tick(ctx, ctx->opt.inflight);  // (one launch = up to 4096 steps: at most four launches queued)
   }
 }
 
@@ -781,7 +805,6 @@ int upload(rmhmc_ctx* ctx, T* dst, const T* src, size_t count) {
 }
 
 int sync(rmhmc_ctx* ctx) {
-  if (ctx->side) HIPCK(hipStreamSynchronize(ctx->side));
   HIPCK(hipStreamSynchronize(ctx->stream));
   HIPCK(hipGetLastError());
   return RMHMC_OK;
@@ -804,7 +827,6 @@ int eval_at(rmhmc_ctx* ctx, const double* w, const double* p, bool sampler_init 
   else HIPCK(hipMemsetAsync(ch.p, 0, sizeof(double) * ctx->n * ctx->DP, ctx->stream));
   fill_int(ctx, ch.phase, 1, ctx->n);
   fill_int(ctx, ch.status, 0, ctx->n);
-  fork_streams(ctx);
   if (sampler_init && ctx->medium) {  // same arithmetic as inside the one-launch steps (bit-exact checkpoint / resume)
     for (Group& g : ctx->groups)
       launch(ctx, g, HEAVY, "medium", [&](hipStream_t st) {
@@ -835,6 +857,17 @@ Chains chains_view(const rmhmc_ctx* ctx, long long off, int n) {
   return v;
 }
 
+// Run-time options that live in device-visible state.  The list of the chains that have just rejected a proposal (k_iter_end appends,
+// k_crestore consumes) exists on the generic multi-launch path with c tiles when cdyn and crestore are on.
+void apply_runtime_options(rmhmc_ctx* ctx) {
+  for (Group& g : ctx->groups) {
+    const bool ok = !ctx->big && !ctx->medium && !ctx->fused && g.ctile && ctx->opt.cdyn && ctx->opt.crestore;
+    g.ch.stale_list = ok ? ctx->stale_list_alloc : nullptr;
+    g.ch.stale_count = ctx->ch.stale_count;
+  }
+  ctx->ch.stale_list = nullptr;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -846,7 +879,21 @@ const char* rmhmc_version(void) { return "rmhmc-hip 0.1 (gfx950, fp64 MFMA)"; }
 const char* rmhmc_last_error(const rmhmc_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64_t n_chains, int32_t dtype, uint32_t flags) {
+  return rmhmc_create_opts(out, device_id, M, D, n_chains, dtype, flags, nullptr, 0);
+}
+
+int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64_t n_chains, int32_t dtype, uint32_t flags,
+                      const rmhmc_option* opts, int32_t n_opts) {
   rmhmc_ctx* ctx = nullptr;  // for the macros: errors go to the global message
+  Options opt{};
+  if (n_opts < 0 || (n_opts > 0 && !opts)) return fail(nullptr, RMHMC_ERR_INVALID, "rmhmc_create_opts: bad option array");
+  for (int i = 0; i < n_opts; ++i) {
+    const OptionDesc* d = find_option(opts[i].key);
+    if (!d) return fail(nullptr, RMHMC_ERR_INVALID, std::string("rmhmc_create_opts: unknown option '") + (opts[i].key ? opts[i].key : "(null)") + "'");
+    if (opts[i].value < d->lo || opts[i].value > d->hi)
+      return fail(nullptr, RMHMC_ERR_INVALID, std::string("rmhmc_create_opts: value out of range for option '") + d->key + "'");
+    opt.*(d->slot) = opts[i].value;
+  }
   if (!out || M <= 0 || D <= 0 || n_chains <= 0) return fail(nullptr, RMHMC_ERR_INVALID, "rmhmc_create: bad shape");
   if (dtype != RMHMC_F64) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: only float64 is built (the reference is float64)");
   if (D > 256) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: D > 256 is not supported (64 < D <= 256 uses the blocked large-D path)");
@@ -863,7 +910,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     return fail(nullptr, RMHMC_ERR_NO_DEVICE, std::string("rmhmc_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
   ctx = new rmhmc_ctx();
   ctx->device = device_id;
-  ctx->M = M; ctx->D = D; ctx->n = n_chains; ctx->flags = flags;
+  ctx->M = M; ctx->D = D; ctx->n = n_chains; ctx->flags = flags; ctx->opt = opt;
   ctx->NB = (D + 15) / 16; ctx->DP = 16 * ctx->NB;
   if (D > 64) {  // large-D path: 64-column blocks, NB = 4 tiles inside a block
     ctx->big = true;
@@ -873,15 +920,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     ctx->NB = 4;
   }
   ctx->Mp = (int)((M + 63) / 64 * 64); ctx->nblk = ctx->Mp / 64;
-  if (const char* e = getenv("RMHMC_CCACHE")) ctx->ccache = atoi(e) != 0;
-  if (const char* e = getenv("RMHMC_CDYN")) ctx->cdyn = atoi(e) != 0;
-  if (const char* e = getenv("RMHMC_CRESTORE")) ctx->crestore = atoi(e) != 0;
-  if (const char* e = getenv("RMHMC_I8_TAIL")) ctx->i8_tail = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("RMHMC_I8_DELTA")) ctx->i8_delta = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("RMHMC_I8_DELTA_INNER")) ctx->i8_delta_inner = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("RMHMC_I8_FORCE_REBASE")) ctx->i8_force_rebase = atoi(e) ? 1 : 0;
   if (flags & RMHMC_FLAG_INT8_INNER_FULL) ctx->i8_inner_drop = 0;
-  if (const char* e = getenv("RMHMC_I8_INNER_DROP")) ctx->i8_inner_drop = atoi(e) ? 1 : 0;
   int rc = RMHMC_OK;
   auto body = [&]() -> int {
     HIPCK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -899,46 +938,33 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     }
     RC(dalloc(ctx, &ch.p, n * DP)); RC(dalloc(ctx, &ch.p0, n * DP)); RC(dalloc(ctx, &ch.Hcur, n)); RC(dalloc(ctx, &ch.Hprop, n));
     RC(dalloc(ctx, &ch.tau, n)); RC(dalloc(ctx, &ch.steps_left, n)); RC(dalloc(ctx, &ch.phase, n)); RC(dalloc(ctx, &ch.status, n)); RC(dalloc(ctx, &ch.cstale, n));
-    RC(dalloc(ctx, &ch.stale_list, n)); RC(dalloc(ctx, &ch.stale_count, (size_t)16));  // (one counter per group)
+    RC(dalloc(ctx, &ch.stale_list, n)); RC(dalloc(ctx, &ch.stale_count, (size_t)1));
+    ctx->stale_list_alloc = ch.stale_list;
     RC(dalloc(ctx, &ch.nsteps_last, n)); RC(dalloc(ctx, &ch.iter, n)); RC(dalloc(ctx, &ch.accepted, n)); RC(dalloc(ctx, &ch.steps_done, n));
     RC(dalloc(ctx, &ch.wq, n * DP)); RC(dalloc(ctx, &ch.uq, n * DP)); RC(dalloc(ctx, &ch.PM, n * DP)); RC(dalloc(ctx, &ch.u0, n * DP));
     RC(dalloc(ctx, &ch.q, n * DP)); RC(dalloc(ctx, &ch.last, n * DP)); RC(dalloc(ctx, &ch.Gq, n * DP * DP));
     RC(dalloc(ctx, &ch.rv0, n * Mp)); RC(dalloc(ctx, &ch.rv2, n * Mp));
-    // chain groups: ping-ponged partitions (RMHMC_GROUPS=1..4).  Measured on MI355X at config 3: no gain (the
-    // co-running light kernels are starved and the heavy ones slow down, profiles/r01_groups_sweep.txt), so
-    // the default is a single group on one stream.
-    int ngroups = 1;
-    if (const char* e = getenv("RMHMC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 4) ngroups = v; }
-    if (n_chains < 64 * ngroups || ctx->big) ngroups = 1;
-    int hiprio = ngroups > 1 ? 1 : 0;
-    if (const char* e = getenv("RMHMC_PRIO")) hiprio = atoi(e) ? 1 : 0;
-    ctx->groups.resize(ngroups);
-    const long long per_group = ((n_chains / ngroups + 63) / 64) * 64;  // leading groups: a multiple of 64 chains
-    for (int gi = 0; gi < ngroups; ++gi) {
-      Group& g = ctx->groups[gi];
-      g.off = std::min<long long>((long long)gi * per_group, n_chains);
-      g.n = (int)((gi == ngroups - 1) ? n_chains - g.off : std::min<long long>(per_group, n_chains - g.off));
-      if (g.n <= 0) return fail(ctx, RMHMC_ERR_INVALID, "internal: empty chain group");
+    ctx->groups.resize(1);
+    {
+      Group& g = ctx->groups[0];
+      g.off = 0;
+      g.n = (int)n_chains;
       // row splits of the 16-chains-per-wave passes: aim at >= ~6000 waves per launch
       const long long cgroups = (g.n + 15) / 16, nb16 = ctx->Mp / 16;
-      long long ns = (6144 / ngroups + cgroups - 1) / cgroups;
+      long long ns = (6144 + cgroups - 1) / cgroups;
       if (ns < 1) ns = 1;
       if (ns > nb16) ns = nb16;
-      {  // ... but no more than 64 splits: the consumers sum the partials serially.  (Round 1 kept up to Mp/16 splits for long data sets
-         // in small batches, when the one-chain-per-wave assembly dominated those shapes anyway; with the row ranges of k_assemble /
-         // k_leverage it is the serial sums that cost: D 64, M 10000, 64 / 128 / 256 chains: 2.44 / 2.28 / 2.52 -> 1.69 / 1.49 / 1.99 ms
-         // per step, the int8 path at 128-512 chains 10-30 % less; profiles/r02_fp64_batch_sweep.txt)
-        long long cap = 64;
-        if (const char* e = getenv("RMHMC_NSPLIT_MAX")) { const long long v = atoll(e); if (v >= 1) cap = v; }
-        if (ns > cap) ns = cap;
-      }
+      // ... but no more than 64 splits (option nsplit_max): the consumers sum the partials serially.  (Round 1 kept up to Mp/16 splits for
+      // long data sets in small batches, when the one-chain-per-wave assembly dominated those shapes anyway; with the row ranges of
+      // k_assemble / k_leverage it is the serial sums that cost: D 64, M 10000, 64 / 128 / 256 chains: 2.44 / 2.28 / 2.52 -> 1.69 / 1.49 /
+      // 1.99 ms per step, the int8 path at 128-512 chains 10-30 % less; profiles/r02_fp64_batch_sweep.txt)
+      if (ns > ctx->opt.nsplit_max) ns = ctx->opt.nsplit_max;
       g.nsplit = (int)ns;
       g.ch = chains_view(ctx, g.off, g.n);
-      g.ch.hiprio = hiprio;
       RC(dalloc(ctx, &g.ch.qpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.gpart, (size_t)g.nsplit * g.n * DP));
       RC(dalloc(ctx, &g.ch.ljl_part, (size_t)g.n * g.nsplit));
-      if (ctx->ccache) RC(dalloc(ctx, &g.ctile, (size_t)((g.n + 15) / 16) * (ctx->Mp / 16) * 64));
+      if (ctx->opt.ccache) RC(dalloc(ctx, &g.ctile, (size_t)((g.n + 15) / 16) * (ctx->Mp / 16) * 64));
       if (!ctx->big) {
         // fp64 assembly (k_assemble: one chain per wavefront over all M rows): below ~1024 chains the launch has fewer wavefronts than
         // the chip has SIMDs, so the rows are cut until ~2048 wavefronts exist (at least 256 rows per range, at most 16 ranges).
@@ -946,17 +972,9 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         const long long waves = g.n;
         long long fs = waves >= 1024 ? 1 : std::min<long long>(16, (2048 + waves - 1) / waves);
         fs = std::min<long long>(fs, std::max(1, ctx->Mp / 256));
-        if (const char* e = getenv("RMHMC_FSPLIT")) { const long long v = atoll(e); if (v >= 1 && v <= 64) fs = v; }
+        if (ctx->opt.fsplit >= 1) fs = ctx->opt.fsplit;
         g.fsplit = (int)fs;
       }
-      if (ngroups > 1) {
-        g.ring.resize(64);
-        for (auto& e : g.ring) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      }
-    }
-    if (ngroups > 1) {
-      HIPCK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-      HIPCK(hipEventCreateWithFlags(&ctx->fj_event, hipEventDisableTiming));
     }
     int i8_slices = (int)((flags >> 12) & 7u);
     if (i8_slices == 0) i8_slices = 6;
@@ -996,7 +1014,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
         RC(dalloc(ctx, &g.vexp, (size_t)g.nCp));
         RC(dalloc(ctx, &g.vexp_d, (size_t)g.nCp)); RC(dalloc(ctx, &g.rebase, (size_t)g.nCp)); RC(dalloc(ctx, &g.dmax, (size_t)1));
-        if (ctx->big && ctx->i8_delta && S == 6) RC(dalloc(ctx, &g.Gbase, (size_t)g.n * ctx->DP * ctx->DP));
+        if (ctx->big && ctx->opt.i8_delta && S == 6) RC(dalloc(ctx, &g.Gbase, (size_t)g.n * ctx->DP * ctx->DP));
         RC(dalloc(ctx, &g.Qs, (size_t)S * ctx->i8_nkp * g.nCp * 32));
         RC(dalloc(ctx, &g.qscale, (size_t)g.nCp));
         // small batches: cut the k range so that about 256 workgroups exist (at least 8 stages per piece, at most 16 pieces; only
@@ -1011,7 +1029,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         g.ksplit_a = pieces((long long)(g.nCp / I8_BM) * (NPp / ctx->i8_bn), ctx->i8_nks);
         g.ksplit_l = pieces((long long)(g.nCp / I8_BM) * (ctx->i8_NRp / ctx->i8_bn), ctx->i8_nkp);
         if (g.ksplit_a > 1) RC(dalloc(ctx, &g.Gpart, (size_t)g.ksplit_a * g.n * ctx->DP * ctx->DP));
-        if (g.ksplit_a == 1 && ctx->i8_bn == 128 && NP % 128 != 0 && ctx->i8_tail != 0) {
+        if (g.ksplit_a == 1 && ctx->i8_bn == 128 && NP % 128 != 0 && ctx->opt.i8_tail != 0) {
           const int ntail = (NP % 128 + 31) / 32;
           g.tail_pieces = (int)std::max<long long>(1, std::min<long long>(8, 256 / ((long long)(g.nCp / I8_BM) * ntail)));
           RC(dalloc(ctx, &g.Tq, (size_t)g.tail_pieces * S * g.nCp * 32 * ntail));
@@ -1051,11 +1069,10 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     RC(dalloc(ctx, &ctx->d_nsteps, n)); RC(dalloc(ctx, &ctx->d_dir, n)); RC(dalloc(ctx, &ctx->d_done, 1)); RC(dalloc(ctx, &ctx->d_steps0, n));
     RC(dalloc(ctx, &ctx->d_miniter, 1));
     RC(dalloc(ctx, &ctx->d_orig, n)); RC(dalloc(ctx, &ctx->d_T, 2 * n));
-    {  // mid-size problems in small batches: one launch per leapfrog step (RMHMC_MEDIUM=0 disables it)
+    {  // mid-size problems in small batches: one launch per leapfrog step (option medium = 0 disables it)
       // measured per global step at one chain (tools/bench_single.py): australian (D = 15) 108 us vs 218 us generic, heart (D = 14)
       // 85 vs 154, german (D = 25) 236 vs 386
-      bool on = !ctx->big && D > FS_D && D <= 32 && ctx->Mp <= MS_MAXMP && n_chains <= 512;
-      if (const char* e = getenv("RMHMC_MEDIUM")) on = on && atoi(e) != 0;
+      const bool on = ctx->opt.medium && !ctx->big && D > FS_D && D <= 32 && ctx->Mp <= MS_MAXMP && n_chains <= 512;
       if (on) {
         const size_t lds = sizeof(double) * (ctx->NB == 1 ? ms_lds_doubles<1>(ctx->Mp) : ms_lds_doubles<2>(ctx->Mp));
         if (ctx->NB == 1) {
@@ -1073,20 +1090,16 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
         ctx->medium_lds = lds;
       }
     }
-    {  // plain HMC in small batches: one launch per trajectory (RMHMC_MEDIUM=0 disables it too)
+    {  // plain HMC in small batches: one launch per trajectory (option medium = 0 disables it too)
       // any batch for short data sets (rows in registers; australian, 8192 chains: 107 M leapfrog-steps/s vs 76 M generic, 2048
       // chains 90 M vs 27 M, tools/bench_hmc_batch.py), small batches otherwise
       long long maxn = ctx->Mp <= 1024 ? (1ll << 40) : 512;
-      if (const char* e = getenv("RMHMC_TRAJ_MAXN")) maxn = atoll(e);
-      bool on = !ctx->big && D <= 32 && n_chains <= maxn;
-      if (const char* e = getenv("RMHMC_MEDIUM")) on = on && atoi(e) != 0;
-      ctx->hmc_traj = on;
+      if (ctx->opt.hmc_traj_maxn >= 0) maxn = ctx->opt.hmc_traj_maxn;
+      ctx->hmc_traj = ctx->opt.medium && !ctx->big && D <= 32 && n_chains <= maxn;
     }
-    {  // small-problem path eligibility (RMHMC_FUSED=0 disables it)
+    {  // small-problem path eligibility (option fused = 0 disables it)
       const size_t lds = ((size_t)(FS_D + 1 + FS_WAVES) * ctx->Mp + (size_t)FS_WAVES * FS_PT) * sizeof(double);
-      bool on = (D <= FS_D) && lds <= 160 * 1024;
-      if (const char* e = getenv("RMHMC_FUSED")) on = on && atoi(e) != 0;
-      if (on) {
+      if (ctx->opt.fused && D <= FS_D && lds <= 160 * 1024) {
         HIPCK(hipFuncSetAttribute((const void*)k_fused_small, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS));
         ctx->fused = true;
         ctx->fused_lds = lds;
@@ -1101,16 +1114,7 @@ int rmhmc_create(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, int64
     rmhmc_destroy(ctx);
     return rc;
   }
-  {  // list of the chains that have just rejected a proposal (k_crestore): generic multi-launch path with c tiles only
-    int gi = 0;
-    for (Group& g : ctx->groups) {
-      const bool ok = !ctx->big && !ctx->medium && !ctx->fused && g.ctile && ctx->cdyn && ctx->crestore && gi < 16;
-      g.ch.stale_count = ctx->ch.stale_count + std::min(gi, 15);
-      if (!ok) g.ch.stale_list = nullptr;
-      ++gi;
-    }
-    ctx->ch.stale_list = nullptr;
-  }
+  apply_runtime_options(ctx);
   *out = ctx;
   return RMHMC_OK;
 }
@@ -1119,10 +1123,7 @@ void rmhmc_destroy(rmhmc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->side) (void)hipStreamSynchronize(ctx->side);
-  for (Group& g : ctx->groups) for (auto& e : g.ring) (void)hipEventDestroy(e);
-  if (ctx->fj_event) (void)hipEventDestroy(ctx->fj_event);
-  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  for (auto& e : ctx->flow) (void)hipEventDestroy(e);
   for (auto& kv : ctx->events) for (auto& e : kv.second) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (void* p : ctx->allocs) (void)hipFree(p);
@@ -1130,18 +1131,59 @@ void rmhmc_destroy(rmhmc_ctx* ctx) {
   delete ctx;
 }
 
+int rmhmc_set_option(rmhmc_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx) return fail(nullptr, RMHMC_ERR_INVALID, "set_option: null context");
+  const OptionDesc* d = find_option(key);
+  if (!d) return fail(ctx, RMHMC_ERR_INVALID, std::string("set_option: unknown option '") + (key ? key : "(null)") + "'");
+  if (d->create_only) return fail(ctx, RMHMC_ERR_INVALID, std::string("set_option: '") + key + "' shapes the context and can only be given to rmhmc_create_opts");
+  if (value < d->lo || value > d->hi) return fail(ctx, RMHMC_ERR_INVALID, std::string("set_option: value out of range for '") + key + "'");
+  HIPCK(hipSetDevice(ctx->device));
+  HIPCK(hipStreamSynchronize(ctx->stream));
+  ctx->opt.*(d->slot) = value;
+  apply_runtime_options(ctx);
+  if (ctx->stale_list_alloc) {  // a list left over from a run with the other setting must not be consumed
+    HIPCK(hipMemsetAsync(ctx->ch.stale_count, 0, sizeof(int), ctx->stream));
+    fill_int(ctx, ctx->ch.cstale, 1, ctx->n);  // (every chain's tiles count as stale: the next first pass recomputes them)
+    HIPCK(hipStreamSynchronize(ctx->stream));
+  }
+  return RMHMC_OK;
+}
+int rmhmc_get_option(rmhmc_ctx* ctx, const char* key, int64_t* value_out) {
+  if (!ctx || !value_out) return fail(ctx, RMHMC_ERR_INVALID, "get_option: null pointer");
+  const OptionDesc* d = find_option(key);
+  if (!d) return fail(ctx, RMHMC_ERR_INVALID, std::string("get_option: unknown option '") + (key ? key : "(null)") + "'");
+  *value_out = ctx->opt.*(d->slot);
+  return RMHMC_OK;
+}
+int rmhmc_options(rmhmc_ctx* ctx, char* buf, size_t len) {
+  if (!ctx || !buf || !len) return fail(ctx, RMHMC_ERR_INVALID, "options: bad argument");
+  std::string o;
+  for (const OptionDesc& d : kOptions) o += (o.empty() ? "" : " ") + std::string(d.key) + "=" + std::to_string(ctx->opt.*(d.slot));
+  snprintf(buf, len, "%s", o.c_str());
+  return RMHMC_OK;
+}
+
 int rmhmc_device_info(rmhmc_ctx* ctx, char* buf, size_t len) {
   if (!ctx || !buf) return fail(ctx, RMHMC_ERR_INVALID, "device_info: bad argument");
   hipDeviceProp_t prop;
   HIPCK(hipGetDeviceProperties(&prop, ctx->device));
-  snprintf(buf, len, "%s %s, %d CUs, %.0f MHz, %.1f GiB; M=%lld (padded %d) D=%d (padded %d, %d MFMA tiles) chains=%lld in %d group(s)%s",
+  snprintf(buf, len, "%s %s, %d CUs, %.0f MHz, %.1f GiB; M=%lld (padded %d) D=%d (padded %d, %d MFMA tiles) chains=%lld%s",
            prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0,
-           (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n, (int)ctx->groups.size(), ctx->fused ? ", fused small-problem path" : "");
+           (long long)ctx->M, ctx->Mp, ctx->D, ctx->DP, ctx->NB * (ctx->NB + 1) / 2, (long long)ctx->n,
+           ctx->fused ? ", fused small-problem path" : ctx->medium ? ", one-launch step" : ctx->big ? ", blocked large-D path" : "");
   if (ctx->i8_requested) {
     const size_t k = strlen(buf);
     snprintf(buf + k, len > k ? len - k : 0, "; int8 metric path %d slices: %s (certificate %.2e%s)", ctx->i8S,
              ctx->i8 ? "active" : "NOT certified for this data, fp64 matrix cores used", ctx->i8_bound,
              ctx->have_data ? "" : ", no data yet");
+  }
+  {
+    const size_t k = strlen(buf);
+    if (len > k + 12) {
+      snprintf(buf + k, len - k, "; options: ");
+      const size_t k2 = strlen(buf);
+      (void)rmhmc_options(ctx, buf + k2, len - k2);
+    }
   }
   return RMHMC_OK;
 }
@@ -1200,7 +1242,7 @@ int rmhmc_set_data(rmhmc_ctx* ctx, const double* X, const double* t, double alph
       for (size_t b = 0; b <= a; ++b, ++q)
         bound = std::max(bound, std::ldexp((double)ctx->i8S * (double)M, ze[q] - 8 * ctx->i8S) / std::sqrt(g0[a] * g0[b]));
     // (delta assembly at the end of a step: the slice products dropped from the difference add to those dropped from the base matrix)
-    if (ctx->i8_delta && ctx->i8S == 6) bound *= (2.0 * ctx->i8S - 1.0) / ctx->i8S;
+    if (ctx->opt.i8_delta && ctx->i8S == 6) bound *= (2.0 * ctx->i8S - 1.0) / ctx->i8S;
     ctx->i8_bound = bound;
     const bool ok = !(ctx->flags & RMHMC_FLAG_INT8_CERTIFY) || bound <= RMHMC_INT8_CERTIFY_TOL;
     if (!ok && ctx->big && !ctx->d_hpart) RC(dalloc(ctx, &ctx->d_hpart, (size_t)ctx->npairs * ctx->n * Mp));
@@ -1221,7 +1263,6 @@ int rmhmc_log_posterior(rmhmc_ctx* ctx, const double* w, double* ljl_out) {
   if (!w || !ljl_out) return fail(ctx, RMHMC_ERR_INVALID, "log_posterior: null pointer");
   ctx->chains_ready = false;
   RC(eval_at(ctx, w, nullptr));
-  join_streams(ctx);
   RC(download(ctx, ljl_out, ctx->ch.trj.ljl, ctx->n));
   return sync(ctx);
 }
@@ -1235,7 +1276,6 @@ int rmhmc_metric(rmhmc_ctx* ctx, const double* w, double* G_out, double* half_lo
   int rc_eval = eval_at(ctx, w, nullptr);
   ctx->want_G = false;
   RC(rc_eval);
-  join_streams(ctx);
   if (G_out)
     for (int64_t c = 0; c < ctx->n; ++c)  // strip the padding: [DP][DP] -> [D][D]
       HIPCK(hipMemcpy2DAsync(G_out + c * ctx->D * ctx->D, ctx->D * 8, (ctx->big ? ctx->d_Gcopy : ctx->ch.Gq) + c * ctx->DP * ctx->DP, ctx->DP * 8, ctx->D * 8, ctx->D,
@@ -1257,7 +1297,6 @@ int rmhmc_metric_terms(rmhmc_ctx* ctx, const double* w, const double* p, double*
   if (!w) return fail(ctx, RMHMC_ERR_INVALID, "metric_terms: null pointer");
   ctx->chains_ready = false;
   RC(eval_at(ctx, w, p));
-  join_streams(ctx);
   if (trace_out) RC(download_vec(ctx, trace_out, ctx->ch.trj.tr));
   if (quad_out && p) RC(download_vec(ctx, quad_out, ctx->ch.last));
   return sync(ctx);
@@ -1288,7 +1327,6 @@ int rmhmc_leapfrog(rmhmc_ctx* ctx, double* w, double* p, double eps, const int32
         hipLaunchKernelGGL(k_park_finished, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.n, g.ch);
       });
   }
-  join_streams(ctx);
   RC(download_vec(ctx, w, ctx->ch.trj.w));
   RC(download_vec(ctx, p, ctx->ch.p));
   if (half_logdet_out) RC(download(ctx, half_logdet_out, ctx->ch.trj.hld, ctx->n));
@@ -1306,7 +1344,6 @@ static int init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] or NU
   }
   if (ctx->fused) {  // the fused path evaluates its own initial record (same arithmetic as inside its steps)
     RC(upload_vec(ctx, ctx->ch.cur.w, theta0_host));
-    fork_streams(ctx);
     for (Group& g : ctx->groups) {
       FusedParams fp{};
       fp.ip = iter_params(ctx, g, IterBase{0, 0, 0, nullptr, false, false});
@@ -1320,7 +1357,6 @@ static int init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] or NU
     RC(eval_at(ctx, theta0_host, nullptr, true));
     for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_commit_all, ctx->D, ctx->DP, g.ch);
   }
-  join_streams(ctx);
   fill_int(ctx, ctx->ch.phase, 0, ctx->n);
   fill_int(ctx, ctx->ch.steps_left, 0, ctx->n);
   fill_int(ctx, ctx->ch.status, 0, ctx->n);
@@ -1344,7 +1380,6 @@ int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u
   RC(upload(ctx, ctx->d_gdir, g_dir, ctx->n));
   RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
   const IterBase ib{1, 0, 0, nullptr, true, false};
-  fork_streams(ctx);
   if (ctx->fused) {
     launch_fused(ctx, ib, L);
   } else {
@@ -1355,7 +1390,6 @@ int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u
       launch_iter_end(ctx, ib);
     }
   }
-  join_streams(ctx);
   std::vector<long long> acc(ctx->n);
   RC(download_vec(ctx, w, ctx->ch.cur.w));
   RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
@@ -1385,8 +1419,8 @@ struct StepGraph {
 static bool step_graph_usable(const rmhmc_ctx* ctx, long long nsteps) {
   if (ctx->groups.size() != 1 || ctx->timing || nsteps < 8) return false;
   if (ctx->fused && ctx->sampler == 0) return false;
-  if (const char* e = getenv("RMHMC_GRAPH")) return atoi(e) != 0;
-  return true;
+  if (ctx->medium && ctx->sampler == 0) return false;  // (the global step is ONE launch there: a one-node graph only costs its instantiation)
+  return ctx->opt.graph != 0;
 }
 static bool build_step_graph(rmhmc_ctx* ctx, const IterBase& ib, StepGraph& sg) {
   if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
@@ -1398,15 +1432,14 @@ static bool build_step_graph(rmhmc_ctx* ctx, const IterBase& ib, StepGraph& sg) 
 // nsteps global steps of the generic path (graph replay when it pays, plain launches otherwise)
 static void run_generic_steps(rmhmc_ctx* ctx, const IterBase& ib, long long nsteps, StepGraph* sg) {
   if (sg && sg->exec) {
-    for (long long s = 0; s < nsteps; ++s) (void)hipGraphLaunch(sg->exec, ctx->stream);
+    for (long long s = 0; s < nsteps; ++s) { (void)hipGraphLaunch(sg->exec, ctx->stream); flow_tick(ctx); }
   } else {
-    for (long long s = 0; s < nsteps; ++s) launch_global_step(ctx, ib);
+    for (long long s = 0; s < nsteps; ++s) { launch_global_step(ctx, ib); flow_tick(ctx); }
   }
 }
 
 // number of chains that reached the iteration limit and the completed transitions of the slowest chain, in one round trip
 static int poll_progress(rmhmc_ctx* ctx, int* done, long long* min_iter) {
-  join_streams(ctx);
   HIPCK(hipMemsetAsync(ctx->d_miniter, 0xff, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(k_min_iter, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ch.iter, (size_t)ctx->n, ctx->d_miniter);
   unsigned long long mi = 0;
@@ -1454,7 +1487,6 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
   const bool ticking = progress_ticking(ctx);
   const long long chunk = ticking ? std::max<long long>(8, ctx->progress_every * (ctx->L + 1) / 2) : min_steps;  // ~ one report per chunk
   StepGraph sg;
-  fork_streams(ctx);
   if (!fused && step_graph_usable(ctx, std::min(min_steps, chunk))) (void)build_step_graph(ctx, ib, sg);
   for (long long left = min_steps; left > 0;) {
     const long long k = std::min(left, chunk);
@@ -1464,7 +1496,6 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
     if (ticking && left > 0) {
       RC(poll_progress(ctx, &done, &min_iter));
       RC(progress_fire(ctx, min_iter));
-      fork_streams(ctx);
     }
   }
   for (;;) {
@@ -1473,7 +1504,6 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
     if (done >= ctx->n) break;
     long long next = std::max(poll, ib.limit - min_iter);
     if (ticking) next = std::min(next, chunk);
-    fork_streams(ctx);
     if (fused) launch_fused(ctx, ib, next);
     else run_generic_steps(ctx, ib, next, &sg);
     s += next;
@@ -1485,11 +1515,18 @@ static int run_until_done(rmhmc_ctx* ctx, const IterBase& ib, long long min_step
 // Every chain from exactly `from` to exactly ib.limit completed transitions.  With a progress callback and ONE chain the run is cut
 // at the milestones first, first+every, ...: the callback gets the exact counters there, as the reference prints them, and the run goes
 // on; the results do not depend on it (the randomness is keyed by chain and iteration).  Several chains: see progress_fire.
-static int run_phase(rmhmc_ctx* ctx, const IterBase& ib, long long from) {
+// A milestone that coincides with a phase boundary (burn_in + 1 completed transitions) is reported on the side of the burn-in banner
+// where the reference prints it: rmhmc.py:38-45 prints at the TOP of the next iteration, i.e. after the banner of :194-196
+// (at_from of phase B); hmc.py:85-94 prints at the bottom of the iteration itself, just before the banner (at_limit of phase A).
+static int run_phase(rmhmc_ctx* ctx, const IterBase& ib, long long from, bool at_from = false, bool at_limit = false) {
   if (ctx->progress_fn && ctx->progress_every > 0 && ctx->n == 1) {
     long long m = ctx->progress_first;
-    if (from >= m) m += ((from - m) / ctx->progress_every + 1) * ctx->progress_every;
-    for (; m < ib.limit; m += ctx->progress_every) {
+    if (from > m) m += ((from - m + ctx->progress_every - 1) / ctx->progress_every) * ctx->progress_every;   // first milestone >= from
+    if (m == from) {
+      if (at_from) RC(report_progress(ctx, RMHMC_EV_PROGRESS, m));
+      m += ctx->progress_every;
+    }
+    for (; m < ib.limit || (at_limit && m == ib.limit); m += ctx->progress_every) {
       IterBase seg = ib;
       seg.limit = m;
       HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
@@ -1529,7 +1566,6 @@ static int run_sorted_phase(rmhmc_ctx* ctx, const IterBase& ib, const std::vecto
   const long long chunk = ticking ? std::max<long long>(8, ctx->progress_every * (ctx->L + 1) / 2) : Tmax + 1;
   int done = 0;
   long long mi = 0;
-  fork_streams(ctx);
   {
     StepGraph sg;
     if (step_graph_usable(ctx, std::min(Tmin, chunk))) (void)build_step_graph(ctx, ib, sg);
@@ -1537,7 +1573,7 @@ static int run_sorted_phase(rmhmc_ctx* ctx, const IterBase& ib, const std::vecto
       const long long k = std::min(left, chunk);
       run_generic_steps(ctx, ib, k, &sg);
       left -= k;
-      if (ticking) { RC(poll_progress(ctx, &done, &mi)); RC(progress_fire(ctx, mi)); fork_streams(ctx); }
+      if (ticking) { RC(poll_progress(ctx, &done, &mi)); RC(progress_fire(ctx, mi)); }
     }
     HIPCK(hipStreamSynchronize(ctx->stream));  // (the graph goes out of scope)
   }
@@ -1547,7 +1583,8 @@ static int run_sorted_phase(rmhmc_ctx* ctx, const IterBase& ib, const std::vecto
     const int nar = std::min(n, (na + 127) / 128 * 128);
     if (nar == n) launch_global_step(ctx, ib);
     else launch_global_step_prefix(ctx, ib, nar);
-    if (ticking && (s - Tmin) % chunk == chunk - 1) { RC(poll_progress(ctx, &done, &mi)); RC(progress_fire(ctx, mi)); fork_streams(ctx); }
+    flow_tick(ctx);
+    if (ticking && (s - Tmin) % chunk == chunk - 1) { RC(poll_progress(ctx, &done, &mi)); RC(progress_fire(ctx, mi)); }
   }
   RC(poll_progress(ctx, &done, &mi));
   RC(progress_fire(ctx, mi));
@@ -1565,7 +1602,7 @@ static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const do
   std::vector<double> th_perm;
   bool sorted = ctx->sampler == 0 && ctx->groups.size() == 1 && !ctx->fused && n >= 2 && n_iter > burn_in + 1;
   ctx->progress_next = ctx->progress_first;
-  if (const char* e = getenv("RMHMC_SORTED")) sorted = sorted && atoi(e) != 0;
+  sorted = sorted && ctx->opt.sorted;
   if (sorted) {
     hipLaunchKernelGGL(k_traj_steps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)ctx->seed,
                        (long long)ctx->chain_offset, ctx->L, (long long)burn_in + 1, (long long)n_iter, (size_t)n, ctx->d_T);
@@ -1599,7 +1636,7 @@ static int sample_core(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, const do
     if (n_iter > burn_in + 1) {
       const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
       if (sorted) RC(run_sorted_phase(ctx, ipB, T));
-      else RC(run_phase(ctx, ipB, burn_in + 1));
+      else RC(run_phase(ctx, ipB, burn_in + 1, true));
     }
     RC(sync(ctx));
     if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1731,14 +1768,12 @@ static int hmc_init_chains(rmhmc_ctx* ctx, const double* theta0_host /* [n][D] o
   if (!theta0_host) { th.assign((size_t)ctx->n * ctx->D, 0.0); theta0_host = th.data(); }
   RC(upload_vec(ctx, ctx->ch.trj.w, theta0_host));
   fill_int(ctx, ctx->ch.phase, 1, ctx->n);
-  fork_streams(ctx);
   if (ctx->hmc_traj) {
     for (Group& g : ctx->groups) launch_hmc_traj(ctx, g, 1);
   } else {
     for (Group& g : ctx->groups) launch_rowpass<RP_G>(ctx, g, g.ch.trj.w, nullptr);
     for (Group& g : ctx->groups) SMALL(ctx, g, "small", k_hmc_init, ctx->dd, g.ch, g.nsplit);
   }
-  join_streams(ctx);
   fill_int(ctx, ctx->ch.phase, 0, ctx->n);
   fill_int(ctx, ctx->ch.steps_left, 0, ctx->n);
   fill_int(ctx, ctx->ch.status, 0, ctx->n);
@@ -1762,9 +1797,7 @@ int rmhmc_hmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const doubl
     RC(upload(ctx, ctx->d_ulen, u_len, ctx->n));
     RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
     const IterBase ib{1, 0, 0, nullptr, true, false};
-    fork_streams(ctx);
     for (int s = 0; s < L; ++s) launch_hmc_global_step(ctx, ib);
-    join_streams(ctx);
     std::vector<long long> acc(ctx->n);
     RC(download_vec(ctx, w, ctx->ch.cur.w));
     RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
@@ -1796,15 +1829,20 @@ int rmhmc_hmc_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, int32_t L,
   int rc = [&]() -> int {
     RC(hmc_init_chains(ctx, theta0));
     const IterBase ipA{burn_in + 1, burn_in, S, d_samples, false, true};
-    RC(run_phase(ctx, ipA, 0));
+    RC(run_phase(ctx, ipA, 0, false, true));
     HIPCK(hipMemcpyAsync(ctx->d_steps0, ctx->ch.steps_done, sizeof(long long) * ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->d_done, 0, sizeof(int), ctx->stream));
     RC(sync(ctx));
     if (ctx->progress_fn) RC(report_progress(ctx, RMHMC_EV_BURNIN_DONE, burn_in + 1));  // hmc.py:92-94
     const auto t0 = std::chrono::steady_clock::now();
     if (n_iter > burn_in + 1) {
+      // hmc.py:83-89 reports during burn-in only (`elif` of the save branch): no milestones, hence no cuts, inside TimeTaken
+      const rmhmc_progress_fn fn = ctx->progress_fn;
+      ctx->progress_fn = nullptr;
       const IterBase ipB{n_iter, burn_in, S, d_samples, false, true};
-      RC(run_phase(ctx, ipB, burn_in + 1));
+      const int rcB = run_phase(ctx, ipB, burn_in + 1);
+      ctx->progress_fn = fn;
+      RC(rcB);
     }
     RC(sync(ctx));
     if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1856,9 +1894,7 @@ int rmhmc_mmala_transition(rmhmc_ctx* ctx, double* w, const double* z, const dou
   RC(upload(ctx, ctx->d_z, z, (size_t)ctx->n * ctx->D));
   RC(upload(ctx, ctx->d_uacc, u_acc, ctx->n));
   const IterBase ib{1, 0, 0, nullptr, true, false};
-  fork_streams(ctx);
   launch_mmala_step(ctx, ib);
-  join_streams(ctx);
   std::vector<long long> acc(ctx->n);
   RC(download_vec(ctx, w, ctx->ch.cur.w));
   RC(download(ctx, acc.data(), ctx->ch.accepted, ctx->n));
@@ -1882,14 +1918,10 @@ int rmhmc_mmala_sample(rmhmc_ctx* ctx, int64_t n_iter, int64_t burn_in, double e
   int rc = [&]() -> int {
     RC(mmala_init(ctx, theta0));
     const IterBase ib{n_iter, burn_in, S, d_samples, false, false};
-    fork_streams(ctx);
-    for (int64_t it = 0; it <= burn_in; ++it) launch_mmala_step(ctx, ib);
-    join_streams(ctx);
+    for (int64_t it = 0; it <= burn_in; ++it) { launch_mmala_step(ctx, ib); flow_tick(ctx); }
     RC(sync(ctx));
     const auto t0 = std::chrono::steady_clock::now();
-    fork_streams(ctx);
-    for (int64_t it = burn_in + 1; it < n_iter; ++it) launch_mmala_step(ctx, ib);
-    join_streams(ctx);
+    for (int64_t it = burn_in + 1; it < n_iter; ++it) { launch_mmala_step(ctx, ib); flow_tick(ctx); }
     RC(sync(ctx));
     if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     HIPCK(hipMemcpyAsync(samples_out, d_samples, sizeof(double) * (size_t)ctx->n * S * ctx->D, hipMemcpyDeviceToHost, ctx->stream));
@@ -1916,7 +1948,6 @@ int rmhmc_chains_run(rmhmc_ctx* ctx, int64_t n_steps) {
   NEED_DATA(ctx);
   if (!ctx->chains_ready) return fail(ctx, RMHMC_ERR_INVALID, "chains_run: rmhmc_chains_init has not been called");
   const IterBase ib{(long long)1 << 62, 0, 0, nullptr, false, false};
-  fork_streams(ctx);
   {
     Timed t(ctx, "total", ctx->stream);
     if (ctx->fused) {
@@ -1927,7 +1958,6 @@ int rmhmc_chains_run(rmhmc_ctx* ctx, int64_t n_steps) {
       run_generic_steps(ctx, ib, n_steps, &sg);
       HIPCK(hipStreamSynchronize(ctx->stream));  // the graph is destroyed at the end of this scope
     }
-    join_streams(ctx);
   }
   return sync(ctx);
 }

@@ -13,7 +13,7 @@ from . import _capi
 
 
 def HMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=100, StepSize=0.14, *, n_chains=1, seed=None,
-        theta0=None, alpha=100.0, device=0, chain_offset=0, verbose=True, return_info=False, _lib=None):
+        theta0=None, alpha=100.0, device=0, chain_offset=0, verbose=True, return_info=False, options=None, _lib=None):
     """ HAMILTONIAN MONTE CARLO (Bayesian logistic regression, N(0, alpha I) prior) """
     XX = np.ascontiguousarray(XX, dtype=np.float64)
     if XX.ndim != 2:
@@ -27,7 +27,7 @@ def HMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=100, StepSi
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 62))
     lib = _lib if _lib is not None else _capi.load_hip_library()
-    with lib.context(N, D, n_chains, flags=0, device=device) as ctx:
+    with lib.context(N, D, n_chains, flags=0, device=device, options=options) as ctx:
         ctx.set_data(XX, t, alpha)
         if verbose:  # the reference's stdout, hmc.py:85-89,92-94
             from .rmhmc import progress_printer

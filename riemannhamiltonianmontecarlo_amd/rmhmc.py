@@ -21,6 +21,7 @@ Keyword-only extensions (defaults preserve the one-chain contract):
   int8_slices  metric assembly on the int8 matrix cores (include/rmhmc.h, RMHMC_FLAG_INT8_METRIC): 4..7 byte slices per
              operand, 0 = fp64 matrix cores, None (default) = 6 slices (G to 2e-14, the level of fp64 summation) when the
              path applies (8 < D <= 256) and there is enough work for its tiles (n_chains * N * D^2 >= 1e9), else fp64
+  options    dict of the library's tuning options (include/rmhmc.h, rmhmc_create_opts), e.g. {"graph": 0}
   return_info  also return a dict(accepted=..., leapfrog_steps=...)
 
 Documented deviations: row 0 of wSaved is undefined in the reference (np.empty,
@@ -56,7 +57,7 @@ def progress_printer(n_chains, hmc_burn_in=None):
 
 def RMHMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=6, StepSize=0.5, NumOfNewtonSteps=4, *,
           n_chains=1, seed=None, compat=True, theta0=None, alpha=100.0, device=0, chain_offset=0, verbose=True,
-          return_info=False, int8_slices=None, _lib=None):
+          return_info=False, int8_slices=None, options=None, _lib=None):
     """ RIEMANNIAN HAMILTONIAN MONTE CARLO (Bayesian logistic regression, N(0, alpha I) prior) """
     XX = np.ascontiguousarray(XX, dtype=np.float64)
     if XX.ndim != 2:
@@ -72,7 +73,7 @@ def RMHMC(XX, t, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=6, StepSi
         seed = int(np.random.randint(0, 2 ** 62))
     lib = _lib if _lib is not None else _capi.load_hip_library()
     flags = (_capi.COMPAT if compat else 0) | _capi.auto_metric_flags(D, n_chains, int8_slices, M=N)
-    with lib.context(N, D, n_chains, flags=flags, device=device) as ctx:
+    with lib.context(N, D, n_chains, flags=flags, device=device, options=options) as ctx:
         ctx.set_data(XX, t, alpha)
         if verbose:
             ctx.set_progress(progress_printer(n_chains))

@@ -44,6 +44,57 @@ def test_bench_two_ranks_gloo():
     assert "cpu_baseline" not in out
 
 
+def test_bench_four_ranks_gloo_small_shards():
+    """The rank count rehearsed beyond two (the GPU box allows at most 6 processes on its card, so 4 ranks stand in for config 4's 8):
+    `bench.py --gpus 4 --chains 128`, gloo collectives, every rank's shard on the one GPU; global chain ids rank*128.., one gather."""
+    out = _run_bench(["--steps", "3", "--warmup", "1", "--workload", "c2", "--chains", "128", "--ess-iters", "10", "--no-cpu-baseline",
+                      "--no-alternates", "--option", "inflight=16"], nproc=4, env_extra={"BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 4 and out["config"]["chains_total"] == 512 and out["gathered_chains"] == 512 and out["all_finite"]
+    assert out["config"]["options"]["inflight"] == 16 and out["config"]["options"]["graph"] == 1
+    assert out["min_ess"]["chains"] == 512
+
+
+def _sharded_worker(rank, world, port, outfile, gather):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from riemannhamiltonianmontecarlo_amd.multi_gpu import sample_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    XX, t = synthetic_logreg(300, 12, 4)
+    # the product library (default lib) under a gloo process group: outputs are written in HBM and hop to the host for the gather
+    out = sample_sharded(XX if rank == 0 else None, t if rank == 0 else None, 7, NumOfIterations=24, BurnIn=8, seed=5, compat=False,
+                         gather=gather)
+    if rank == 0:
+        payload, secs, info = out
+        if gather == "samples":
+            np.savez(outfile, samples=payload, acc=info["accepted"], steps=info["leapfrog_steps"])
+        else:
+            np.savez(outfile, **payload)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gather", ["samples", "summary"])
+def test_sample_sharded_hip_library_under_gloo(hip, tmp_path, gather):
+    """sample_sharded with the HIP library and a non-nccl backend handed host tensors to the _dev entry points.  Three
+    ranks (a ragged split of 7 chains: 3 + 2 + 2) on the one GPU, data broadcast from rank 0: bit-equal to one context."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_sharded_worker, args=(3, port, out, gather), nprocs=3, join=True)
+    XX, t = synthetic_logreg(300, 12, 4)
+    with hip.context(300, 12, 7, flags=0) as ctx:
+        ctx.set_data(XX, t)
+        smp, acc, steps, _ = ctx.sample(24, 8, seed=5)
+    g = np.load(out)
+    if gather == "samples":
+        assert np.array_equal(g["samples"], smp) and np.array_equal(g["acc"], acc) and np.array_equal(g["steps"], steps)
+    else:
+        assert np.allclose(g["mean"], smp.mean(1), rtol=1e-12, atol=1e-14) and g["min_ess"].shape == (7,)
+
+
 def test_bench_default_line_shape():
     """The N = 1 line on a small workload: every object the measurement contract names is present and self-consistent."""
     out = _run_bench(["--steps", "3", "--warmup", "1", "--workload", "c1", "--ess-iters", "30"])
@@ -202,3 +253,14 @@ def test_hmc_shim_prints_like_the_reference(hip, capsys):
     assert out[2] == "50 iterations completed." and out[3].startswith("Acceptance: ") and 0.0 <= float(out[3].split()[1]) <= 1.0
     assert out[4] == "Burn-in complete, now drawing posterior samples."
     assert len(out) == 6 and out[5].startswith("Time drawing posterior: ")
+    # BurnIn a multiple of 50 (the default 1000 is one): the report of iteration BurnIn comes just before the banner (hmc.py:85-94)
+    HMC(XX, t, NumOfIterations=120, BurnIn=50, NumOfLeapFrogSteps=20, StepSize=0.05, seed=2)
+    out = capsys.readouterr().out.splitlines()
+    assert [o for o in out if not o.startswith("Acceptance")][:3] == ["0 iterations completed.", "50 iterations completed.",
+                                                                      "Burn-in complete, now drawing posterior samples."]
+    assert len(out) == 6
+    # RMHMC with BurnIn % 50 == 48: the print of iteration BurnIn + 1 follows the banner (rmhmc.py:38 prints at the top of the iteration)
+    from riemannhamiltonianmontecarlo_amd import RMHMC
+    RMHMC(XX, t, NumOfIterations=110, BurnIn=48, seed=2)
+    out = [o for o in capsys.readouterr().out.splitlines() if not o.startswith("Acceptance")]
+    assert out[:3] == ["Burn-in complete, now drawing posterior samples.", "50 iterations completed.", "100 iterations completed."]

@@ -18,8 +18,8 @@ SHAPES = [(1000, 64, 130), (690, 15, 5), (203, 33, 7), (129, 48, 300), (532, 12,
           (20, 10, 3), (33, 16, 130), (64, 17, 1), (97, 64, 129)]   # one / two k-stages, single chain, tile edges
 
 
-def _run(lib, M, D, n, XX, t, fn, flags):
-    with lib.context(M, D, n, flags=flags) as ctx:
+def _run(lib, M, D, n, XX, t, fn, flags, options=None):
+    with lib.context(M, D, n, flags=flags, options=options) as ctx:
         ctx.set_data(XX, t, 100.0)
         return fn(ctx)
 
@@ -176,7 +176,7 @@ def test_full_size_config3(hip, oracle):
 
 
 @pytest.mark.parametrize("M,D,n,S", [(400, 40, 300, 6), (1000, 40, 2432, 6), (400, 40, 300, 5), (900, 64, 2100, 6)])
-def test_ragged_pair_block_as_tiles_of_its_own_is_bit_identical(hip, monkeypatch, M, D, n, S):
+def test_ragged_pair_block_as_tiles_of_its_own_is_bit_identical(hip, M, D, n, S):
     """The pairs beyond the last full block of 128 (D = 64: 2080 = 16 x 128 + 32) run as two-wave tiles of their own, k range in
     pieces summed as integers (k_assemble_i8_tail / _tailsum): same bits as the one-launch form, for one and for several pieces
     (2432 chains x 7 pair blocks and 2100 x 17: no k split of the main launch, 4 / 3 tail pieces)."""
@@ -186,8 +186,7 @@ def test_ragged_pair_block_as_tiles_of_its_own_is_bit_identical(hip, monkeypatch
     dirs = np.where(rs.rand(n) < 0.5, -1, 1).astype(np.int32)
     out = {}
     for tail in ("0", "1"):
-        monkeypatch.setenv("RMHMC_I8_TAIL", tail)
-        with hip.context(M, D, n, flags=_capi.int8_metric_flags(S)) as ctx:
+        with hip.context(M, D, n, flags=_capi.int8_metric_flags(S), options={"i8_tail": int(tail)}) as ctx:
             ctx.set_data(XX, t, 100.0)
             out[tail] = ctx.metric(w) + ctx.leapfrog(w, p, 0.5, dirs, 2, 4)
     for a, b in zip(out["0"], out["1"]):
@@ -224,9 +223,9 @@ def test_inner_iterates_from_five_slices(hip, oracle, M, D, n):
 # (D > 64: the large-D path, whose slices are cut by k_vsplit and whose base matrix is a copy - Gq is factored in place)
 @pytest.mark.parametrize("M,D,n", [(900, 64, 2100), (203, 33, 7), (400, 40, 2432), (129, 48, 300), (600, 96, 140), (900, 130, 260),
                                    (1200, 256, 130)])
-def test_delta_assembly_at_the_end_of_a_step(hip, oracle, monkeypatch, M, D, n):
+def test_delta_assembly_at_the_end_of_a_step(hip, oracle, M, D, n):
     """The metric of the evaluation that ends a leapfrog step is G(last position iterate) plus the assembly of the DIFFERENCE of
-    the two v vectors, cut into as few slices as its largest element needs (launch_assemble / I8Delta; RMHMC_I8_DELTA=0 turns it
+    the two v vectors, cut into as few slices as its largest element needs (launch_assemble / I8Delta; option i8_delta = 0 turns it
     off).  Integer arithmetic on the same grids: theta / p / log det after three steps agree with the full assembly to the fp64
     rounding of one addition per step times the conditioning of the problem (`delta_end`: 3e-14; 3e-12 at M = 129 < 3 D; asserted
     1e-10), also when every chain is treated as re-based (its slices hold N itself and its G is overwritten: the path of a chain
@@ -242,17 +241,13 @@ def test_delta_assembly_at_the_end_of_a_step(hip, oracle, monkeypatch, M, D, n):
         return ctx.leapfrog(w, p, 0.5, dirs, 3, 4)
 
     out = {}
-    variants = (("full", {"RMHMC_I8_DELTA": "0"}, 0.0),
-                ("delta_end", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "0"}, 1e-10),
-                ("rebase_end", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "0", "RMHMC_I8_FORCE_REBASE": "1"}, 1e-10),
-                ("delta", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "1"}, 5e-10),
-                ("rebase", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "1", "RMHMC_I8_FORCE_REBASE": "1"}, 5e-10))
-    for name, env, _ in variants:
-        for k in ("RMHMC_I8_FORCE_REBASE", "RMHMC_I8_DELTA_INNER"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        out[name] = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(6))
+    variants = (("full", {"i8_delta": 0}, 0.0),
+                ("delta_end", {"i8_delta": 1, "i8_delta_inner": 0}, 1e-10),
+                ("rebase_end", {"i8_delta": 1, "i8_delta_inner": 0, "i8_force_rebase": 1}, 1e-10),
+                ("delta", {"i8_delta": 1, "i8_delta_inner": 1}, 5e-10),
+                ("rebase", {"i8_delta": 1, "i8_delta_inner": 1, "i8_force_rebase": 1}, 5e-10))
+    for name, opts, _ in variants:
+        out[name] = _run(hip, M, D, n, XX, t, fn, _capi.int8_metric_flags(6), options=opts)
     ref = _run(oracle, M, D, n, XX, t, fn, 0)
     assert any(not np.array_equal(a, b) for a, b in zip(out["full"], out["delta_end"]))   # (the delta paths are really in use)
     assert any(not np.array_equal(a, b) for a, b in zip(out["delta_end"], out["delta"]))

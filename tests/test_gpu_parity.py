@@ -265,33 +265,9 @@ def test_errors(hip):
             ctx.chains_run(1)                       # chains_init not called
 
 
-@pytest.mark.parametrize("D,extra", [(40, 0), (40, _capi.int8_metric_flags(6)), (20, 0)])
-def test_two_group_pingpong_matches_oracle(hip, oracle, monkeypatch, D, extra):
-    """Large batches are split into two chain groups ping-ponged over two HIP streams; force that
-    scheduling at a small size and check transitions, the sampler and the stepping API against the oracle
-    (D = 40: generic kernels, with the fp64 and with the int8 matrix-core passes; D = 20: the one-launch step)."""
-    monkeypatch.setenv("RMHMC_GROUPS", "2")
-    M, n = 500, 150
-    rs = np.random.RandomState(21)
-    w = 0.1 * rs.randn(n, D); z = rs.randn(n, D); ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
-
-    def fn(ctx):
-        if "MFMA" in ctx.device_info():   # the HIP library (the oracle reports its OpenMP threads)
-            assert "2 group" in ctx.device_info()
-        r = ctx.transition(w, z, ul, gd, ua, L=4, eps=0.5, K=4)
-        s = ctx.sample(6, 2, L=3, seed=5, chain_offset=7)
-        return r, s
-
-    (rg, sg), (ro, so) = _both(hip, oracle, M, D, n, fn, flags=_capi.COMPAT | extra)
-    assert np.array_equal(rg["nsteps"], ro["nsteps"]) and np.array_equal(rg["accepted"], ro["accepted"])
-    assert rel_err(rg["w_prop"], ro["w_prop"]) < TOL_TRAJ and rel_err(rg["p_prop"], ro["p_prop"]) < TOL_TRAJ
-    assert rel_err(rg["w"], ro["w"]) < TOL_TRAJ
-    assert np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2]) and rel_err(sg[0], so[0]) < 1e-7
-
-
 @pytest.mark.parametrize("M,D,n,flags", [(1000, 8, 37, _capi.COMPAT), (532, 8, 9, 0), (300, 5, 6, _capi.COMPAT), (70, 1, 4, 0),
                                          (1500, 3, 5, _capi.COMPAT)])
-def test_fused_small_path_matches_oracle_and_generic(hip, oracle, monkeypatch, M, D, n, flags):
+def test_fused_small_path_matches_oracle_and_generic(hip, oracle, M, D, n, flags):
     """BASELINE config-2 path (D <= 8, X in LDS, one fused kernel for many steps): whole sampled chains against
     the oracle (same Philox streams) and against the generic multi-kernel path."""
     def fn(ctx):
@@ -302,15 +278,14 @@ def test_fused_small_path_matches_oracle_and_generic(hip, oracle, monkeypatch, M
         return info, r, ctx.chains_state()
 
     (ig, rg, sg), (io, ro, so) = _both(hip, oracle, M, D, n, fn, flags=flags, seed=9)
-    assert "fused" in ig
+    assert "fused small-problem path" in ig
     assert np.array_equal(rg[1], ro[1]) and np.array_equal(rg[2], ro[2])
     assert rel_err(rg[0], ro[0]) < 1e-7
     assert np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2]) and rel_err(sg[0], so[0]) < 1e-7
-    monkeypatch.setenv("RMHMC_FUSED", "0")
     XX, t = synthetic_logreg(M, D, 9)
-    with hip.context(M, D, n, flags=flags) as ctx:
+    with hip.context(M, D, n, flags=flags, options={"fused": 0}) as ctx:
         ctx.set_data(XX, t)
-        assert "fused" not in ctx.device_info()
+        assert "fused small-problem path" not in ctx.device_info() and ctx.get_option("fused") == 0
         r2 = ctx.sample(12, 3, L=4, seed=23, chain_offset=5)
     assert np.array_equal(r2[1], rg[1]) and rel_err(r2[0], rg[0]) < 1e-7
 
@@ -491,16 +466,16 @@ def test_checkpoint_resume(hip):
 
 
 @pytest.mark.parametrize("M,D,n", [(690, 15, 5), (1000, 25, 3), (270, 14, 70), (50, 9, 2), (2048, 32, 4)])
-def test_medium_one_launch_step_matches_generic_and_oracle(hip, oracle, monkeypatch, M, D, n):
+def test_medium_one_launch_step_matches_generic_and_oracle(hip, oracle, M, D, n):
     """8 < D <= 32 in small batches: the whole leapfrog step runs in one launch per chain (csrc/medium_step.hip.h).  Same inputs
-    through that path, through the generic kernels (RMHMC_MEDIUM=0) and through the oracle."""
+    through that path, through the generic kernels (option medium = 0) and through the oracle."""
     XX, t = synthetic_logreg(M, D, 11)
     rs = np.random.RandomState(M + D)
     w = 0.2 * rs.randn(n, D) / np.sqrt(D); z = rs.randn(n, D)
     ul = rs.rand(n); gd = rs.randn(n); ua = rs.rand(n)
 
-    def run(lib, flags):
-        with lib.context(M, D, n, flags=flags) as ctx:
+    def run(lib, flags, options=None):
+        with lib.context(M, D, n, flags=flags, options=options) as ctx:
             ctx.set_data(XX, t)
             r = ctx.transition(w, z, ul, gd, ua, L=5, eps=0.4, K=4)
             s = ctx.sample(12, 4, 3, 0.4, 4, seed=5)
@@ -508,9 +483,7 @@ def test_medium_one_launch_step_matches_generic_and_oracle(hip, oracle, monkeypa
 
     for flags in (0, _capi.COMPAT):
         rm, sm = run(hip, flags)
-        monkeypatch.setenv("RMHMC_MEDIUM", "0")
-        rg, sg = run(hip, flags)
-        monkeypatch.delenv("RMHMC_MEDIUM")
+        rg, sg = run(hip, flags, {"medium": 0})
         ro, so = run(oracle, flags)
         for other_r, other_s in ((rg, sg), (ro, so)):
             assert np.array_equal(rm["nsteps"], other_r["nsteps"]) and np.array_equal(rm["accepted"], other_r["accepted"])
@@ -522,24 +495,22 @@ def test_medium_one_launch_step_matches_generic_and_oracle(hip, oracle, monkeypa
 
 
 @pytest.mark.parametrize("M,D,n", [(690, 15, 4), (1000, 25, 3), (250, 7, 9), (3000, 30, 2)])
-def test_hmc_one_launch_trajectory_matches_generic_and_oracle(hip, oracle, monkeypatch, M, D, n):
+def test_hmc_one_launch_trajectory_matches_generic_and_oracle(hip, oracle, M, D, n):
     """Plain HMC in small batches runs a whole trajectory per launch (k_hmc_traj); same inputs through the five-launches-per-step
-    generic kernels (RMHMC_MEDIUM=0) and the oracle."""
+    generic kernels (option medium = 0) and the oracle."""
     XX, t = synthetic_logreg(M, D, 12)
     rs = np.random.RandomState(M)
     w = 0.1 * rs.randn(n, D); z = rs.randn(n, D); ul = rs.rand(n); ua = rs.rand(n)
 
-    def run(lib):
-        with lib.context(M, D, n, flags=0) as ctx:
+    def run(lib, options=None):
+        with lib.context(M, D, n, flags=0, options=options) as ctx:
             ctx.set_data(XX, t)
             r = ctx.hmc_transition(w, z, ul, ua, L=12, eps=0.02)
             s = ctx.hmc_sample(20, 5, 10, 0.02, seed=8)
         return r, s
 
     rt, st = run(hip)
-    monkeypatch.setenv("RMHMC_MEDIUM", "0")
-    rg, sg = run(hip)
-    monkeypatch.delenv("RMHMC_MEDIUM")
+    rg, sg = run(hip, {"medium": 0})
     ro, so = run(oracle)
     for r2, s2 in ((rg, sg), (ro, so)):
         assert np.array_equal(rt["nsteps"], r2["nsteps"]) and np.array_equal(rt["accepted"], r2["accepted"])
@@ -548,7 +519,7 @@ def test_hmc_one_launch_trajectory_matches_generic_and_oracle(hip, oracle, monke
         assert np.array_equal(st[1], s2[1]) and np.array_equal(st[2], s2[2]) and rel_err(st[0], s2[0]) < 1e-8
 
 
-def test_small_batch_row_split_of_the_fp64_assembly(hip, oracle, monkeypatch):
+def test_small_batch_row_split_of_the_fp64_assembly(hip, oracle):
     """Fewer chains than SIMDs: k_assemble cuts the data rows into ranges (planes summed in a fixed order) so that the fp64 step time is
     monotone in the batch size.  Same G as the unsplit kernel to summation-order rounding, same parity with the oracle,
     and bit-reproducible from run to run."""
@@ -557,16 +528,12 @@ def test_small_batch_row_split_of_the_fp64_assembly(hip, oracle, monkeypatch):
     rs = np.random.RandomState(1)
     w = 0.1 * rs.randn(n, D) / np.sqrt(D); p = rs.randn(n, D)
 
-    def run(lib, env):
-        if env is not None:
-            monkeypatch.setenv("RMHMC_FSPLIT", env)
-        else:
-            monkeypatch.delenv("RMHMC_FSPLIT", raising=False)
-        with lib.context(M, D, n, flags=0) as ctx:
+    def run(lib, fsplit):
+        with lib.context(M, D, n, flags=0, options=None if fsplit is None else {"fsplit": fsplit}) as ctx:
             ctx.set_data(XX, t)
             return ctx.metric(w) + ctx.leapfrog(w, p, 0.4, 1, 2, 4)
 
-    split, split2, whole, ref = run(hip, None), run(hip, None), run(hip, "1"), run(oracle, None)
+    split, split2, whole, ref = run(hip, None), run(hip, None), run(hip, 1), run(oracle, None)
     for a, b in zip(split, split2):
         assert np.array_equal(a, b)
     assert not np.array_equal(split[0], whole[0])                       # the split is really on for 70 chains (different summation order)
@@ -595,7 +562,7 @@ def test_fixed_point_count_and_trajectory_length_edge_cases(hip, oracle, K, L):
 
 @pytest.mark.parametrize("M,D,n,fl", [(600, 40, 300, 0), (600, 40, 300, _capi.int8_metric_flags(6)), (500, 12, 40, _capi.COMPAT),
                                        (400, 100, 20, 0)])
-def test_work_sorted_sampler_is_bit_identical(hip, monkeypatch, M, D, n, fl):
+def test_work_sorted_sampler_is_bit_identical(hip, M, D, n, fl):
     """The bulk sampler lays the chains out in order of decreasing post-burn-in work (the trajectory lengths are drawn independently of
     the state, so they are known beforehand) and shrinks the launches of the tail with the prefix of chains still running.  Chains are
     independent and keyed by their index in the caller's order: samples, acceptance counts, step counts and the device statistics must
@@ -604,9 +571,10 @@ def test_work_sorted_sampler_is_bit_identical(hip, monkeypatch, M, D, n, fl):
     th = 0.01 * np.random.RandomState(0).randn(n, D)
 
     def run(env):
-        monkeypatch.setenv("RMHMC_SORTED", env)
         with hip.context(M, D, n, flags=fl) as ctx:
             ctx.set_data(XX, t)
+            ctx.set_option("sorted", int(env))            # (a run-time option: rmhmc_set_option)
+            assert ctx.options()["sorted"] == int(env)
             a = ctx.sample(40, 12, 6, 0.4, 4, seed=21, chain_offset=5, theta0=th)
             b = ctx.sample_stats(40, 12, 6, 0.4, 4, seed=21, chain_offset=5, theta0=th)
         return a, b
@@ -620,47 +588,56 @@ def test_work_sorted_sampler_is_bit_identical(hip, monkeypatch, M, D, n, fl):
     assert np.array_equal(b1["accepted"], a1) and np.array_equal(b1["leapfrog_steps"], st1)
 
 
-def test_c_cache_and_graph_replay_do_not_change_results(hip, monkeypatch):
-    """k_mompass with c = v(1-2p) cached per position (RMHMC_CCACHE, default on) against recomputing it in every pass, and the global step
-    replayed from a hipGraph (RMHMC_GRAPH, default on) against plain launches: same chains."""
+def test_c_cache_and_graph_replay_do_not_change_results(hip):
+    """k_mompass with c = v(1-2p) cached per position (option ccache, default on) against recomputing it in every pass, and the global step
+    replayed from a hipGraph (option graph, default on) against plain launches, with and without the flow control that bounds the number
+    of steps in flight (option inflight): same chains."""
     M, D, n = 900, 50, 200
     XX, t = synthetic_logreg(M, D, 9)
 
-    def run(**env):
-        for k in ("RMHMC_CCACHE", "RMHMC_GRAPH"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with hip.context(M, D, n, flags=0) as ctx:
+    def run(create=None, **runtime):
+        with hip.context(M, D, n, flags=0, options=create) as ctx:
             ctx.set_data(XX, t)
+            for k, v in runtime.items():
+                ctx.set_option(k, v)
             ctx.chains_init(seed=4, L=6, eps=0.4, K=4)
             ctx.chains_run(24)
             return ctx.chains_state()
 
-    base, nograph, nocache = run(), run(RMHMC_GRAPH="0"), run(RMHMC_CCACHE="0")
-    for a, b in zip(base, nograph):
-        assert np.array_equal(a, b)
+    base, nograph, nocache = run(), run(graph=0), run({"ccache": 0})
+    for other in (nograph, run(inflight=0), run(inflight=4), run(graph=0, inflight=1)):
+        for a, b in zip(base, other):
+            assert np.array_equal(a, b)
+    with hip.context(M, D, n, flags=0) as ctx:           # create-time keys are refused later on, unknown keys always
+        for bad in (("ccache", 0), ("no_such_option", 1), ("graph", 2)):
+            with pytest.raises(_capi.RmhmcError):
+                ctx.set_option(*bad)
+    with pytest.raises(_capi.RmhmcError):
+        hip.context(M, D, n, flags=0, options={"no_such_option": 1})
     assert np.array_equal(base[1], nocache[1]) and np.array_equal(base[2], nocache[2])     # same transitions, same accept decisions
     assert rel_err(base[0], nocache[0]) < 1e-11
 
 
 @pytest.mark.parametrize("flags", [0, _capi.int8_metric_flags(6)])
-def test_first_momentum_pass_reuses_c_tiles_bit_identically(hip, monkeypatch, flags):
+def test_first_momentum_pass_reuses_c_tiles_bit_identically(hip, flags):
     """The first momentum pass of a step takes c from the tiles the previous evaluation left behind, per wavefront, unless one of its chains
-    has just rejected a proposal (k_mompass<.., 3>, Chains::cstale); RMHMC_CDYN=0 recomputes c in that pass for everybody.  Same bits either
+    has just rejected a proposal (k_mompass<.., 3>, Chains::cstale); option cdyn = 0 recomputes c in that pass for everybody
+    (crestore = 0: the wavefronts holding a rejecting chain recompute, instead of k_crestore for the listed chains).  Same bits either
     way, with rejections in the run (step size 0.9: acceptance well below 1)."""
     M, D, n = 700, 40, 300
     XX, t = synthetic_logreg(M, D, 11)
 
-    def run(cdyn):
-        monkeypatch.setenv("RMHMC_CDYN", cdyn)
+    def run(cdyn, crestore=1):
         with hip.context(M, D, n, flags=flags) as ctx:
             ctx.set_data(XX, t)
+            ctx.set_option("cdyn", cdyn); ctx.set_option("crestore", crestore)
             ctx.chains_init(seed=8, L=4, eps=0.9, K=4)
             ctx.chains_run(40)
             return ctx.chains_state()
 
-    a, b = run("1"), run("0")
+    a, b = run(1), run(0)
+    for x, y in zip(a, run(1, 0)):
+        assert np.array_equal(x, y)
     iters, acc = a[1], a[2]
     assert (acc < iters).any() and acc.sum() > 0          # some proposals rejected, some accepted
     for x, y in zip(a, b):

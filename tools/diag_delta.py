@@ -18,12 +18,11 @@ for (M, D, n) in [(129, 48, 300), (203, 33, 7), (900, 64, 2100), (400, 40, 2432)
     dirs = np.where(rs.rand(n) < 0.5, -1, 1).astype(np.int32)
     for ns in (1, 2, 3):
         res = {}
-        for name, env, fl in (("full", {"RMHMC_I8_DELTA": "0"}, 0), ("delta", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "1"}, 0),
-                              ("delta_end", {"RMHMC_I8_DELTA": "1", "RMHMC_I8_DELTA_INNER": "0"}, 0),
-                              ("full_innerfull", {"RMHMC_I8_DELTA": "0"}, _capi.FLAG_INT8_INNER_FULL), ("fp64", {}, None)):
-            os.environ.update(env)
+        for name, opts, fl in (("full", {"i8_delta": 0}, 0), ("delta", {"i8_delta": 1, "i8_delta_inner": 1}, 0),
+                               ("delta_end", {"i8_delta": 1, "i8_delta_inner": 0}, 0),
+                               ("full_innerfull", {"i8_delta": 0}, _capi.FLAG_INT8_INNER_FULL), ("fp64", {}, None)):
             flags = 0 if fl is None else (_capi.int8_metric_flags(6) | fl)
-            with hip.context(M, D, n, flags=flags) as ctx:
+            with hip.context(M, D, n, flags=flags, options=opts or None) as ctx:
                 ctx.set_data(XX, t, 100.0)
                 res[name] = ctx.leapfrog(w, p, 0.5, dirs, ns, 4)
         nn = min(n, 64)

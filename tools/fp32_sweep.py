@@ -10,7 +10,6 @@ import time
 
 import numpy as np
 
-os.environ["RMHMC_FUSED"] = "0"   # the D <= 8 fused kernel has no fp32 mode: compare the generic kernels
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402,F401
@@ -25,7 +24,7 @@ for M, D, n in ((1000, 8, 1024), (10000, 16, 1024), (10000, 64, 2048), (50000, 6
     w = 0.05 * rs.randn(n, D); p = np.sqrt(M / 4.0) * rs.randn(n, D)   # momentum of the metric's scale
     out, ms = [], []
     for flags in (0, _capi.FLAG_FP32_METRIC):
-        with lib.context(M, D, n, flags=flags) as ctx:
+        with lib.context(M, D, n, flags=flags, options={"fused": 0}) as ctx:   # the D <= 8 fused kernel has no fp32 mode: compare the generic kernels
             ctx.set_data(XX, t)
             out.append(ctx.leapfrog(w, p, 0.5, 1, 1, 4))
             ctx.chains_init(theta0=w, seed=1)
