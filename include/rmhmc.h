@@ -73,13 +73,15 @@ typedef struct rmhmc_ctx rmhmc_ctx;
                                           instead.  Without this bit the int8 path is used unconditionally (explicit request).
                                           The Python shims set it whenever they choose the int8 path by themselves. */
 #define RMHMC_INT8_CERTIFY_TOL 1e-9
-#define RMHMC_FLAG_INT8_INNER_FULL (1u << 10) /* with RMHMC_FLAG_INT8_METRIC at 6 slices: also sum the metric of the position fixed-point
-                                          ITERATES before the last one (rmhmc.py:116-122, FixedIter = 1 .. K-2) from all 6 slices.  By
-                                          default those assemblies, whose G only steers the next iterate, use the 5 most significant
-                                          slices of the same operands (15 slice products instead of 21; G of an iterate to ~5e-12);
-                                          the last iterate, every evaluation point (G, log det, gradient, leverages: everything that
-                                          enters the Hamiltonian and rmhmc_metric) always use all 6.  Effect on theta after a step:
-                                          < 1e-11 relative (tests/test_gpu_int8_metric.py); 6 % fewer ms per step at config 3. */
+#define RMHMC_FLAG_INT8_INNER_FULL (1u << 10) /* with RMHMC_FLAG_INT8_METRIC at 6 slices: sum EVERY integer GEMM from all 6 slices.  By default
+                                          two kinds of quantity that only steer the trajectory and enter no Hamiltonian use the 5 most
+                                          significant slices of the same operands (15 slice products instead of 21, ~5e-12 instead of
+                                          ~3e-14): the metric of the position fixed-point ITERATES before the last one (rmhmc.py:116-122,
+                                          FixedIter = 1 .. K-2: it only steers the next iterate) and the leverages x_n' G^-1 x_n behind the
+                                          trace term tr(G^-1 dG/dw_d) (rmhmc.py:64-77,142-156: it only enters the momentum updates).  The
+                                          last iterate and every evaluation point (G, log det, gradient: everything that enters the
+                                          Hamiltonian and rmhmc_metric) always use all 6.  Effect on theta / p after a step: < 1e-11
+                                          relative (tests/test_gpu_int8_metric.py). */
 #define RMHMC_FLAG_MMALA_FULL (1u << 6)  /* rmhmc_mmala_*: the full manifold MALA of BLR_mMALA.m (drift with the metric-
                                           derivative terms) instead of the simplified one of BLR_mMALA_Simp.m */
 #define RMHMC_FLAG_ESS_WRAP (1u << 9)     /* rmhmc_ess / rmhmc_sample_stats: autocorrelations exactly as the reference's PYTHON

@@ -218,6 +218,62 @@ __device__ __forceinline__ void digits6_to_z(const unsigned (&Qd)[6], double (&z
   for (int r = 0; r < 4; ++r) z[r] = __hiloint2double((int)H[r], (int)L[r]);
 }
 
+// p = 1 / (1 + e^-f), v = p (1 - p), c = v (1 - 2 p) for the four values of an accumulator tile (rmhmc.py:52-53,67,117-118,135-136,148), written
+// as four dependency chains side by side.  The element-wise part of the row passes runs on the fp64 pipe the matrix instructions use, two
+// wavefronts per SIMD, so what counts is the instruction count and that a chain's ~8-cycle latencies are filled by the other three:
+//   e^-f  = 2^n e^r, n = rint(-f log2 e), r = -f - n ln 2 in two pieces, e^r by its Taylor polynomial to r^13 (|r| <= 0.3466: truncation
+//           4e-18), ldexp: 18 instructions; overflow / underflow / NaN fall out of ldexp and the arithmetic (e^-f = inf for f < -709.78,
+//           as np.exp gives the reference);
+//   1 / d = rcp + two Newton steps (d = 1 + e^-f >= 1; an infinite d is clamped to 2^1000, i.e. p = 2^-1000 where the reference has 0).
+// Within one ulp of the library exp and the IEEE quotient it replaces (39 -> 34 instructions per value, no branches).  EVERY generic-path
+// kernel that needs p, v or c at a position goes through this function (k_rowpass, k_mompass, k_crestore), so that a c tile is the same
+// bits whoever computed it (tests: test_first_momentum_pass_reuses_c_tiles_bit_identically).
+__device__ __forceinline__ void sigmoid4(const d4& F, d4& p, d4& v, d4& c) {
+  double dn[4], t[4], q[4], x[4], nn[4];
+  // (|f| beyond 2^40 - a diverged chain - is clamped: the range reduction below is exact up to |n| < 2^53, and e^-f is 0 or inf long
+  //  before; fmin / fmax drop a NaN, so f - f, which is NaN for a non-finite f and 0 otherwise, carries it into d)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { x[r] = fmin(fmax(-F[r], -0x1p40), 0x1p40); nn[r] = F[r] - F[r]; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dn[r] = __builtin_rint(x[r] * 0x1.71547652b82fep+0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = fma(-dn[r], 0x1.62e42fefa39efp-1, x[r]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = fma(-dn[r], 0x1.abc9e3b39803fp-56, t[r]);
+  constexpr double ck[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                             1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0,      0.5};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = ck[0];
+#pragma unroll
+  for (int k = 1; k < 12; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = fma(q[r], t[r], ck[k]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = fma(q[r], t[r], 1.0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = fma(q[r], t[r], 1.0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = ldexp(q[r], (int)dn[r]);            // e^-f
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = q[r] > 0x1p1000 ? 0x1p1000 : q[r];   // (a NaN stays a NaN)
+  double d[4], rc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) d[r] = (1.0 + q[r]) + nn[r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rc[r] = __builtin_amdgcn_rcp(d[r]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rc[r] = fma(fma(-d[r], rc[r], 1.0), rc[r], rc[r]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    p[r] = rc[r];
+    const double om = 1.0 - rc[r];
+    v[r] = rc[r] * om;
+    c[r] = v[r] * fma(-2.0, rc[r], 1.0);
+  }
+}
+
 // log(1 + e^f) and e^f / (1 + e^f) of the log joint and its gradient (rmhmc.py:100,140,167-168) from p = 1 / (1 + e^-f), which the row
 // pass has at hand, instead of a second exp, an ocml log and a second divide (148 -> 77 fp64 instructions per data row in k_rowpass<RP_F>,
 // whose time is the fp64 VALU's):  e^f / (1 + e^f) = p,  log(1 + e^f) = max(f, 0) - log(y) with y = p (f >= 0) or 1 - p (f < 0), y in
@@ -354,28 +410,43 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
       }
   };
   auto xrow = [&](int n, int I) { return *(const double*)((const char*)(dd.Xr + (size_t)n * DP + I) + xr_off); };
-  // element-wise part of one tile: F -> v, c (and softplus / residual); rows nl + 2 r + h
-  auto elem = [&](const d4& F, const d4& tq, int nl, int h, d4& vv, d4& cc, d4& rn) {
+  // element-wise part of one tile: F -> p, v, c (sigmoid4) and, for RP_F / RP_G, the terms of the log joint and of its gradient
+  // (rmhmc.py:100,140,167-168); rows nl + 2 r + h.  log(1 + e^f) = max(f, 0) - log y with y = p (f >= 0) or 1 - p (f < 0) in [1/2, 1], so
+  // the lane's share of the log joint is  sum (f t - max(f, 0)) + log(prod y):  one multiplication per row and one log per LJ_FLUSH
+  // blocks (the product of 8 LJ_FLUSH factors >= 1/2 cannot underflow) instead of a logarithm per row.  Padded rows (x = 0, t = 0) have
+  // f = 0: they add nothing to the sum and a factor 1/2 each to the product, which is taken out again at the end (npad ln 2).  Where
+  // e^f overflows (f > 709.78) the reference gets log(1 + e^f) = inf and e^f / (1 + e^f) = NaN: the largest f of the lane's rows is
+  // kept and the lane's log-joint and gradient partials are set to -inf / NaN after the loop.
+  constexpr int LJ_FLUSH = 64;
+  double ly = 1.0, fhi = 0.0;
+  auto elem = [&](const d4& F, const d4& tq, d4& vv, d4& cc, d4& rn) {
+    d4 pp;
+    sigmoid4(F, pp, vv, cc);
+    if (MODE != RP_V) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nl + 2 * r + h;
-      const double f = F[r];
-      const double em = exp(-f);
-      const double p = 1.0 / (1.0 + em);
-      const double v = p * (1.0 - p);
-      vv[r] = v;
-      cc[r] = v * (1.0 - 2.0 * p);
-      if (MODE != RP_V) {
-        const double tn = tq[r];
-        double sp, sg;
-        softplus_sigmoid(f, p, sp, sg);
-        if (n < dd.M) lj += f * tn - sp;
-        rn[r] = tn - sg;  // padded rows: x = 0, no contribution
+      for (int r = 0; r < 4; ++r) {
+        const double f = F[r], tn = tq[r];
+        const double y = f >= 0.0 ? pp[r] : 1.0 - pp[r];
+        ly *= y;
+        lj += fma(f, tn, -fmax(f, 0.0));  // (fmax drops a NaN, f t keeps it)
+        fhi = fmax(fhi, f);
+        rn[r] = tn - pp[r];
       }
     }
   };
+  // RP_F / RP_G: w lives in LDS (the lane's own KK values, written and read by the same lane: no barrier), not in 32 registers - with
+  // them the kernel needs ~290 registers and spills.  (Round 2 re-read w from global memory through volatile loads, which the compiler
+  // serialised: sixteen dependent cache round trips in front of the products of every block, the largest single cost of the pass.)
+  __shared__ double s_w[MODE == RP_V ? 1 : 4 * KK * 64];
+  double* const my_w = s_w + (MODE == RP_V ? 0 : ((threadIdx.x >> 6) * KK) * 64 + lane);
+  if constexpr (MODE != RP_V) {
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) my_w[kk * 64] = Wb[kk];
+  }
   if (B0 < B1) load_a(B0, 0, KK);
-  for (int B = B0; B < B1; ++B) {
+  for (int Bc = B0; Bc < B1; Bc += LJ_FLUSH) {
+  const int Be = min(B1, Bc + LJ_FLUSH);
+  for (int B = Bc; B < Be; ++B) {
     const int n0 = 32 * B, nl = n0 + 8 * rr;  // the lane's eight data rows nl .. nl+7
     // gradient operands of a tile are requested just before its element-wise work and land behind it; the two tiles are worked off
     // one after the other to keep the live registers of the exp / softplus code low
@@ -383,10 +454,8 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
     d4 FA = (d4){0.0, 0.0, 0.0, 0.0}, FB = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      // (RP_F: w is read again for every block - 512 cache-resident bytes per wave - instead of living in 32 registers the whole
-      // launch: with them the kernel needs ~290 registers and spills, or runs one wave per SIMD, 1.34 ms against 1.0)
       double wk;
-      if constexpr (MODE == RP_F) wk = *(const volatile double*)(wq + (size_t)cj * DP + 4 * kk + rr);
+      if constexpr (MODE != RP_V) wk = my_w[kk * 64];
       else wk = Wb[kk];
       FA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, wk, FA, 0, 0, 0);
       FB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, wk, FB, 0, 0, 0);
@@ -405,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
     }
     __builtin_amdgcn_sched_barrier(0);
     d4 vA, cA, rnA = (d4){0.0, 0.0, 0.0, 0.0}, vB, cB, rnB = rnA;
-    elem(FA, tA, nl, 0, vA, cA, rnA);
+    elem(FA, tA, vA, cA, rnA);
     if (MODE != RP_V) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -421,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
       if (B + 1 < B1) load_a(B + 1, 0, KK / 2);
       __builtin_amdgcn_sched_barrier(0);
     }
-    elem(FB, tB, nl, 1, vB, cB, rnB);
+    elem(FB, tB, vB, cB, rnB);
     if (MODE != RP_V) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -508,6 +577,8 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
       }
     }
   }
+  if (MODE != RP_V) { lj += log(ly); ly = 1.0; }
+  }
   if (I8 && MODE != RP_G && bad && live) atomicOr(&vs.vbad[cj], 1);
   if constexpr (DELTA) {
     if (!live) dmx = 0.0;
@@ -517,6 +588,20 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
   }
   if (MODE == RP_F && ctile && cstale && live && rr == 0 && split == 0) cstale[cj] = 0;  // (the chain's c tiles are those of this w now)
   if (MODE != RP_V) {
+    {  // the lane's padded rows (n >= M) among nl .. nl + 7 of its blocks: a factor 1/2 each in the products
+      int npad = 0;
+      for (int B = max(B0, (dd.M - 8 * rr - 7) / 32 - 1); B < B1; ++B)
+        npad += max(0, min(8, 32 * B + 8 * rr + 8 - dd.M));
+      lj = fma((double)npad, 0.69314718055994531, lj);
+    }
+    // (f > 709.78 on one of the chain's rows in this split: as the reference's overflowing e^f leaves them)
+    const double fh = fmax(fmax(fhi, __shfl_xor(fhi, 16, 64)), fmax(__shfl_xor(fhi, 32, 64), __shfl_xor(fhi, 48, 64)));
+    const bool ov = fh > 709.782712893384;
+    if (ov) {
+      lj = -__builtin_inf();
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Gr[I] = (d4){__builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
+    }
     lj = col4_sum(lj);
     if (live && rr == 0) ljl_part[(size_t)cj * nsplit + split] = lj;
     if (live) {
@@ -781,12 +866,8 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
     if (B + 1 < B1) load_a(B + 1, 0, KK / 2);  // (the other half once tile A's Q operands are used up: registers)
     __builtin_amdgcn_sched_barrier(0);
     if (CM != 2) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double ea = exp(-FA[r]);
-        const double pa = 1.0 / (1.0 + ea);
-        cA[r] = pa * (1.0 - pa) * (1.0 - 2.0 * pa);
-      }
+      d4 pa, va;
+      sigmoid4(FA, pa, va, cA);
       if (CM == 1) ct[(size_t)(2 * B) * 64] = cA;
     }
 #pragma unroll
@@ -808,12 +889,8 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
     }
     __builtin_amdgcn_sched_barrier(0);
     if (CM != 2) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double eb = exp(-FB[r]);
-        const double pb = 1.0 / (1.0 + eb);
-        cB[r] = pb * (1.0 - pb) * (1.0 - 2.0 * pb);
-      }
+      d4 pb, vb;
+      sigmoid4(FB, pb, vb, cB);
       if (CM == 1) ct[(size_t)(2 * B + 1) * 64] = cB;
     }
 #pragma unroll
@@ -901,16 +978,9 @@ __global__ __launch_bounds__(256, 2) void k_crestore(DevData dd, int n_chains, c
     __builtin_amdgcn_sched_barrier(0);
     if (B + 1 < B1) load_a(B + 1);
     __builtin_amdgcn_sched_barrier(0);
-    d4 cA, cB;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {  // (the expression of mompass_body / k_rowpass: the same bits)
-      const double ea = exp(-FA[r]);
-      const double pa = 1.0 / (1.0 + ea);
-      cA[r] = pa * (1.0 - pa) * (1.0 - 2.0 * pa);
-      const double eb = exp(-FB[r]);
-      const double pb = 1.0 / (1.0 + eb);
-      cB[r] = pb * (1.0 - pb) * (1.0 - 2.0 * pb);
-    }
+    d4 cA, cB, pa, va, pb, vb;
+    sigmoid4(FA, pa, va, cA);  // (the function of mompass_body / k_rowpass: the same bits)
+    sigmoid4(FB, pb, vb, cB);
     if (live) {
       ct[(size_t)(2 * B) * 64] = cA;
       ct[(size_t)(2 * B + 1) * 64] = cB;

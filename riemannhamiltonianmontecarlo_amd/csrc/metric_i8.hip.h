@@ -129,6 +129,10 @@ __device__ __forceinline__ void wait_lgkm(i4v& a, i4v& b, i4v& c) {
   asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
 template <int N>
+__device__ __forceinline__ void wait_lgkm(i4v& a, i4v& b, i4v& c, i4v& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void wait_lgkm(i4v& a, i4v& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
@@ -149,6 +153,18 @@ __device__ __forceinline__ double i8_combine(F&& acc_of) {
 #pragma unroll
   for (int g = S - 1; g >= 0; --g) val = val * 0.00390625 + (double)acc_of(g);
   return val;
+}
+
+// LDS stage buffers of a tile: three (loads two stages ahead), four for the short stages of S <= 4 in the forms whose loads are issued
+// unconditionally (ALLON below).  A stage of S = 4 is 20 MFMAs per wave, ~0.65 us: two of them do not cover the latency of an LDS-DMA
+// load that misses L2 (MFMA busy 61 % against 72-76 % for S = 5, 6 on the same tile); three stages ahead = 128 KB of the 160.
+#ifndef I8_NBUF4
+#define I8_NBUF4 1
+#endif
+template <int S, int WN, int TN>
+constexpr int i8_nbuf() {
+  constexpr int ROWS = I8_BM + 32 * TN * WN, NT = 128 * WN, NU = (2 * ROWS + NT - 1) / NT;
+  return (I8_NBUF4 && S <= 4 && 2 * ROWS == NU * NT && 4 * S * ROWS * 32 <= 140 * 1024) ? 4 : 3;
 }
 
 // RAW: the epilogue gets the int32 accumulators themselves, epi(row, col, g, acc_g), instead of their fp64 combination.
@@ -195,7 +211,9 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
 #ifndef I8_ALLON
 #define I8_ALLON 1
 #endif
-  constexpr bool ALLON = I8_ALLON && (NU == 1) && (2 * ROWS == NT);
+  constexpr bool ALLON = I8_ALLON && (2 * ROWS == NU * NT);
+  constexpr int NBUF = I8_ALLON ? i8_nbuf<S, WN, TN>() : 3, PD = NBUF - 1;  // ring of stage buffers, prefetch distance
+  static_assert(NBUF == 3 || ALLON, "the deeper ring relies on the unconditional issue");
   auto gl1 = [&](int ks, int buf, int s) {  // slice s of stage ks
     if (I8_ABLATE & 1) return;
 #pragma unroll
@@ -228,26 +246,37 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   // wave-uniform.  Only in the 8-wave form: with one wave per SIMD nothing is gained, and a branch around the MFMAs makes the
   // compiler shuttle the AGPR accumulators through VGPR copies (972 v_accvgpr moves in the S = 6 loop, 1.4x slower)
   const bool work = WN != 4 || (wm * 64 < rows_real && wn * 32 * TN < cols_real);
-  gl(0, 0);
-  if (nks > 1) { gl(1, 1); retire_older(); } else wait_vmcnt<0>();
+  if constexpr (NBUF == 3) {
+    gl(0, 0);
+    if (nks > 1) { gl(1, 1); retire_older(); } else wait_vmcnt<0>();
+  } else {  // (ALLON: stages past the end are the last stage again, into buffers nobody reads)
+#pragma unroll
+    for (int d = 0; d < PD; ++d) gl(min(d, nks - 1), d);
+    wait_vmcnt<(PD - 1) * S * NU>();
+  }
   __builtin_amdgcn_s_barrier();
   int cur = 0;
   i4v fb[S][TN], fa[2][2];
   for (int ks = 0; ks < nks; ++ks) {
-    const int nxt = cur == 2 ? 0 : cur + 1, wr = nxt == 2 ? 0 : nxt + 1;
+    const int nxt = cur == NBUF - 1 ? 0 : cur + 1, wr = cur == 0 ? NBUF - 1 : cur - 1;  // wr: the buffer of stage ks - 1, free since the last barrier
     const bool spread = I8_DSPREAD && (WN != 4 || work);  // (waves that skip their MFMAs issue their loads at the top)
-    const int kpre = ALLON ? min(ks + 2, nks - 1) : ks + 2;  // stage to prefetch (ALLON: clamped, always issued)
-    if (!spread && (ALLON || ks + 2 < nks)) gl(kpre, wr);
+    const int kpre = ALLON ? min(ks + PD, nks - 1) : ks + PD;  // stage to prefetch (ALLON: clamped, always issued)
+    if (!spread && (ALLON || ks + PD < nks)) gl(kpre, wr);
     const unsigned char* bc = lds + ((I8_ABLATE & 2) ? 0 : cur) * STAGE;
     if (WN != 4 || work) {
     const bool rd = !(I8_ABLATE & 2) || ks == 0;
-    if (I8_ASMFRAG && TN == 1 && !(I8_ABLATE & 2)) {
-      // read order: A_0 (2), B_{S-1} .. B_0 (S), A_1 (2); group i >= 1 issues A_{i+1} first.  Outstanding reads before the MFMA pair
-      // (0, j): the ones issued after B_j, i.e. j + 2; before group i >= 1: the two of A_{i+1} (none for the last group).
+    if (I8_ASMFRAG && TN <= 2 && 2 + S * TN + 2 <= 15 && !(I8_ABLATE & 2)) {   // (lgkmcnt is a 4-bit counter)
+      // read order: A_0 (2), B_{S-1} .. B_0 (TN each), A_1 (2); group i >= 1 issues A_{i+1} first.  Outstanding reads before the MFMAs
+      // of (0, j): the ones issued after B_j, i.e. TN j + 2; before group i >= 1: the two of A_{i+1} (none for the last group).
       const unsigned aA = (unsigned)(size_t)(lds_ptr_t)(lds) + cur * STAGE + fragA, aB = (unsigned)(size_t)(lds_ptr_t)(lds) + cur * STAGE + fragB;
       fa[0][0] = lds_read_b128<0>(aA);
       fa[0][1] = lds_read_b128<32 * I8_ROWB>(aA);
-      [&]<int... J>(std::integer_sequence<int, J...>) { ((fb[S - 1 - J][0] = lds_read_b128<(S - 1 - J) * ROWS * I8_ROWB>(aB)), ...); }(std::make_integer_sequence<int, S>{});
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        ([&] {
+          fb[S - 1 - J][0] = lds_read_b128<(S - 1 - J) * ROWS * I8_ROWB>(aB);
+          if constexpr (TN == 2) fb[S - 1 - J][TN - 1] = lds_read_b128<(S - 1 - J) * ROWS * I8_ROWB + 32 * I8_ROWB>(aB);
+        }(), ...);
+      }(std::make_integer_sequence<int, S>{});
       [&]<int... I>(std::integer_sequence<int, I...>) {
         ([&] {
           constexpr int i = I;
@@ -255,14 +284,20 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
             fa[(i + 1) & 1][0] = lds_read_b128<(i + 1) * ROWS * I8_ROWB>(aA);
             fa[(i + 1) & 1][1] = lds_read_b128<(i + 1) * ROWS * I8_ROWB + 32 * I8_ROWB>(aA);
           }
-          if (spread && (ALLON || ks + 2 < nks)) gl1(kpre, wr, i);
+          if (spread && (ALLON || ks + PD < nks)) gl1(kpre, wr, i);
           if constexpr (i > 0) wait_lgkm<(i + 1 < S) ? 2 : 0>(fa[i & 1][0], fa[i & 1][1]);
           [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
             ([&] {
               constexpr int j = S - 1 - i - JJ;
-              if constexpr (i == 0) wait_lgkm<j + 2>(fa[0][0], fa[0][1], fb[j][0]);
-              acc[i + j][0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][0], fb[j][0], acc[i + j][0][0], 0, 0, 0);
-              acc[i + j][1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][1], fb[j][0], acc[i + j][1][0], 0, 0, 0);
+              if constexpr (i == 0) {
+                if constexpr (TN == 2) wait_lgkm<TN * j + 2>(fa[0][0], fa[0][1], fb[j][0], fb[j][TN - 1]);
+                else wait_lgkm<j + 2>(fa[0][0], fa[0][1], fb[j][0]);
+              }
+#pragma unroll
+              for (int b = 0; b < TN; ++b) {
+                acc[i + j][0][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][0], fb[j][b], acc[i + j][0][b], 0, 0, 0);
+                acc[i + j][1][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i & 1][1], fb[j][b], acc[i + j][1][b], 0, 0, 0);
+              }
             }(), ...);
           }(std::make_integer_sequence<int, S - i>{});
         }(), ...);
@@ -283,7 +318,7 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
 #pragma unroll
         for (int a = 0; a < 2; ++a) fa[(i + 1) & 1][a] = *(const i4v*)(bc + (i + 1) * ROWS * I8_ROWB + fragA + a * 32 * I8_ROWB);
       }
-      if (spread && (ALLON || ks + 2 < nks)) gl1(kpre, wr, i);
+      if (spread && (ALLON || ks + PD < nks)) gl1(kpre, wr, i);
       if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = S - 1 - i; j >= 0; --j) {
@@ -298,7 +333,8 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
     }
     }
     }
-    if (ALLON || ks + 2 < nks) retire_older(); else wait_vmcnt<0>();
+    if constexpr (NBUF == 3) { if (ALLON || ks + 2 < nks) retire_older(); else wait_vmcnt<0>(); }
+    else wait_vmcnt<(PD - 1) * S * NU>();  // stage ks + 1 has landed; the PD - 1 newer ones may be in flight
     if (!(I8_ABLATE & 4)) __builtin_amdgcn_s_barrier();
     cur = nxt;
   }
@@ -321,7 +357,7 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
 }
 
 template <int S, int WN, int TN>
-constexpr int i8_lds_bytes() { return 3 * S * (I8_BM + 32 * TN * WN) * I8_ROWB; }
+constexpr int i8_lds_bytes() { return i8_nbuf<S, WN, TN>() * S * (I8_BM + 32 * TN * WN) * I8_ROWB; }
 
 // probe / unit-test form (tools/i8_gemm_probe.hip): C[row][col] = sum_g acc_g 2^(-8g)
 template <int S, int WN, int TN, int PIN>

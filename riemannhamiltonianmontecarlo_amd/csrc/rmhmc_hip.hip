@@ -472,7 +472,11 @@ void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w, int cmode) {
 void launch_leverage(rmhmc_ctx* ctx, Group& g) {
   if (ctx->i8) {  // h_n as the transposed sliced GEMM, then tr = X' (c .* h) on the fp64 matrix cores
     launch(ctx, g, HEAVY, "qsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 0))); });
-    launch(ctx, g, HEAVY, "leverage_i8", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 1))); });
+    // The leverages h_n = x_n' G^-1 x_n enter the trace term only, which steers the momentum and appears in no Hamiltonian: like the metric
+    // of an inner position iterate they are summed from the S - 1 most significant slices of the same operands (15 slice products
+    // instead of 21; h to ~3e-12 norm-wise, theta / p after a step move by < 1e-11; RMHMC_FLAG_INT8_INNER_FULL: all S)
+    const int suse = (ctx->i8_inner_drop && ctx->i8S == 6) ? 5 : ctx->i8S;
+    launch(ctx, g, HEAVY, "leverage_i8", [&](hipStream_t st) { I8_SWITCH_S(suse, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 1))); });
     launch(ctx, g, HEAVY, "trvec", [&](hipStream_t st) {
       if (ctx->big) {  // rv0 holds h (one "pair" plane), the large-D trace kernel multiplies by c itself
         dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
@@ -1051,6 +1055,8 @@ int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, 
           I8_SWITCH_S(sv, {
             auto kfn = k_assemble_i8<S_, WN_, TN_>;
             HIPCK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, WN_, TN_>())));
+            auto kfn2 = k_leverage_i8<S_, WN_, TN_>;
+            HIPCK(hipFuncSetAttribute((const void*)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, WN_, TN_>())));
             auto kfn3 = k_assemble_i8_tail<S_>;
             HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
           });

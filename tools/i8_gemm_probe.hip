@@ -113,6 +113,14 @@ int main(int argc, char** argv) {
       run_case<5, 4, 1, 1>(8192, 2080, 10000, false, 5);
       return 0;
     }
+    if (S == 44) {  // 4 slices: the 64 x 64 wave tile (4 waves, 256 accumulators: build WITHOUT -amdgpu-mfma-vgpr-form) against the library's 64 x 32
+      run_case<4, 2, 2, 1>(300, 300, 1000, true, 0);
+      run_case<4, 2, 2, 1>(8192, 2048, 10000, false, 8);
+      run_case<4, 4, 1, 1>(8192, 2048, 10000, false, 8);
+      run_case<4, 2, 2, 1>(8192, 10000, 2080, false, 8);
+      run_case<4, 4, 1, 1>(8192, 10000, 2080, false, 8);
+      return 0;
+    }
     if (S == 5) run_case<5, 4, 1>(8192, 2080, 10000, false, 3);
     if (S == 6) run_case<6, 2, 1>(8192, 2080, 10000, false, 3);
     return 0;

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel stats + PMC FETCH_SIZE/WRITE_SIZE passes) into small text/JSON
-summaries under gpurun_out/ that are then copied into profiles/."""
+"""Condense rocprofv3 CSV output (kernel trace + PMC passes) into small text/JSON summaries under gpurun_out/ that are then copied
+into profiles/.  Every pass of tools/profile.sh starts from the SAME checkpoint of chains at stationarity (bench.py --load-state), so
+durations, cycle counts and bytes belong to the same kind of launch; whatever a pass dispatches before its first global step (set-up,
+the evaluation of the restored point) is dropped: only dispatches from the first k_iter_begin on are counted, and the number of
+k_iter_begin dispatches is the number of global steps (launches per step = calls / steps)."""
 import csv
 import glob
 import json
@@ -25,13 +28,24 @@ def is_gemm(name):
     return "k_assemble_i8" in name
 
 
+def from_first_step(recs, key):
+    """rows ordered by dispatch, from the first k_iter_begin (or one-launch step kernel) on; returns (rows, steps)"""
+    recs = sorted(recs, key=lambda r: int(r[key]))
+    first = next((i for i, r in enumerate(recs) if "k_iter_begin" in r["Kernel_Name"] or "k_step_medium" in r["Kernel_Name"]
+                  or "k_fused_small" in r["Kernel_Name"]), 0)
+    recs = recs[first:]
+    ids = {r["Dispatch_Id"] for r in recs if "k_iter_begin" in r["Kernel_Name"]}
+    return recs, max(1, len(ids))
+
+
 lines = []
 stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
 trace = glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True)
 rows = []
 if trace:
     per = defaultdict(list)
-    for r in csv.DictReader(open(trace[0])):
+    trows, nsteps = from_first_step(list(csv.DictReader(open(trace[0]))), "Dispatch_Id")
+    for r in trows:
         per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     total = float(sum(sum(v) for v in per.values()))
     for name, d in per.items():
@@ -45,9 +59,11 @@ if trace:
     rows.sort(key=lambda r: -r["TotalDurationNs"])
     lines.append("# rocprofv3 --kernel-trace --stats : per-kernel summary from the kernel trace (%s, workload %s)" % (tag, wl))
     lines.append("# (k_assemble_i8*: dispatches of the delta assembly that returned at once are listed as `returned`, not averaged in)")
-    lines.append("%-62s %8s %14s %12s %7s" % ("kernel", "calls", "total_ms", "avg_us", "pct"))
-    for r in rows[:28]:
-        lines.append("%-62s %8s %14.3f %12.1f %7.2f%s" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"] / 1e6, r["AverageNs"] / 1e3, r["Percentage"],
+    lines.append("# %d global steps of chains at stationarity (dispatches before the first k_iter_begin dropped); kernel time per step %.3f ms"
+                 % (nsteps, total / nsteps / 1e6))
+    lines.append("%-62s %8s %9s %14s %12s %7s" % ("kernel", "calls", "per_step", "total_ms", "avg_us", "pct"))
+    for r in rows[:32]:
+        lines.append("%-62s %8s %9.2f %14.3f %12.1f %7.2f%s" % (short(r["Name"]), r["Calls"], r["Calls"] / float(nsteps), r["TotalDurationNs"] / 1e6, r["AverageNs"] / 1e3, r["Percentage"],
                                                          ("   returned at once: %d (%.1f us each)" % (r["Returned"], r["ReturnedNs"] / r["Returned"] / 1e3)) if r["Returned"] else ""))
 elif stats:
     rows = list(csv.DictReader(open(stats[0])))
@@ -62,7 +78,7 @@ for ctr in ("fetch", "write"):
     if not files:
         continue
     agg = defaultdict(lambda: [0.0, 0])
-    recs = list(csv.DictReader(open(files[0])))
+    recs, _ = from_first_step(list(csv.DictReader(open(files[0]))), "Dispatch_Id")
     peak = defaultdict(float)
     for r in recs:
         peak[r["Kernel_Name"]] = max(peak[r["Kernel_Name"]], float(r["Counter_Value"]))
@@ -74,7 +90,7 @@ for ctr in ("fetch", "write"):
     cname = "FETCH_SIZE" if ctr == "fetch" else "WRITE_SIZE"
     lines.append("")
     lines.append("# rocprofv3 --pmc %s : per-kernel average per launch (raw counter, KiB units; FETCH_SIZE must be doubled on gfx950 for wide coalesced reads, MI355X_MICROARCH.md)" % cname)
-    for k, (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
+    for k, (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]:
         lines.append("%-62s launches=%4d  avg_raw=%14.1f KiB" % (k, n, v / n))
         summary.setdefault(cname, {})[k] = {"launches": n, "avg_raw_kib": v / n}
 # matrix-pipe occupancy and effective clock per kernel (SQ cycles are quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs), LDS activity
@@ -87,7 +103,7 @@ for ctr, names in (("mfma", ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")), ("
     if not files:
         continue
     agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    recs = list(csv.DictReader(open(files[0])))
+    recs, _ = from_first_step(list(csv.DictReader(open(files[0]))), "Dispatch_Id")
     peak = defaultdict(float)
     for r in recs:
         peak[(r["Kernel_Name"], r["Counter_Name"])] = max(peak[(r["Kernel_Name"], r["Counter_Name"])], float(r["Counter_Value"]))
@@ -101,7 +117,7 @@ for ctr, names in (("mfma", ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")), ("
         a[0] += float(r["Counter_Value"]); a[1] += 1
     lines.append("")
     lines.append("# rocprofv3 --pmc %s : per-kernel average per launch" % " ".join(names))
-    for k, d in sorted(agg.items(), key=lambda kv: -sum(v[0] for v in kv[1].values()))[:8]:
+    for k, d in sorted(agg.items(), key=lambda kv: -sum(v[0] for v in kv[1].values()))[:14]:
         vals = {n: d[n][0] / max(1, d[n][1]) for n in names if n in d}
         extra = ""
         if ctr == "mfma" and "GRBM_GUI_ACTIVE" in vals and k in kernel_avg_ns:
@@ -119,6 +135,25 @@ if os.path.exists(bj):
         lines.append(open(bj).read().strip())
     except Exception:
         pass
+# roofline.traffic of bench.py: HBM-side bytes of one metric assembly (main launch + the tiles of the ragged pair block + their integer
+# sum), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, + WRITE_SIZE; KiB -> bytes
+if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    tr = {"source": "profiles/%s_%s_pmc.json (tools/profile.sh %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, chains at "
+                    "stationarity from a checkpoint, dispatches from the first global step on)" % (tag, wl, tag),
+          "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md); fabric-side counters, "
+                        "Infinity-Cache hits included"}
+    for S in (4, 5, 6, 7):
+        f = w = 0.0
+        for part in ("k_assemble_i8<%d, 4, 1>" % S, "k_assemble_i8<%d, 2, 1>" % S, "k_assemble_i8_tail<%d>" % S, "k_assemble_i8_tailsum<%d>" % S):
+            f += summary["FETCH_SIZE"].get(part, {}).get("avg_raw_kib", 0.0)
+            w += summary["WRITE_SIZE"].get(part, {}).get("avg_raw_kib", 0.0)
+        if f > 0:
+            tr["assemble_i8_x%d_fetch_raw_kib" % S] = f; tr["assemble_i8_x%d_write_raw_kib" % S] = w
+            tr["assemble_i8_x%d_bytes_per_launch" % S] = (2.0 * f + w) * 1024.0
+    for name in ("k_assemble<4>", "k_assemble<3>", "k_assemble<2>", "k_assemble<1>"):
+        if name in summary["FETCH_SIZE"]:
+            tr["assemble_bytes_per_launch"] = (2.0 * summary["FETCH_SIZE"][name]["avg_raw_kib"] + summary["WRITE_SIZE"].get(name, {}).get("avg_raw_kib", 0.0)) * 1024.0
+    json.dump(tr, open(os.path.join(out, "traffic_%s.json" % wl), "w"), indent=1)
 open(os.path.join(out, "summary_%s_%s.txt" % (tag, wl)), "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(os.path.join(out, "summary_%s_%s.json" % (tag, wl)), "w"), indent=1)
 print("\n".join(lines))
