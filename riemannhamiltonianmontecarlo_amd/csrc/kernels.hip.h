@@ -58,6 +58,10 @@ struct Chains {
   // chains that have just rejected a proposal (k_iter_end appends, k_crestore at the start of the next step recomputes their c tiles
   // and empties the list); null where no c tiles are kept
   int *stale_list, *stale_count;
+  // int8 metric path, generic kernels: flags / maxima that the row passes raise with atomics and the assemblies read are cleared by the
+  // per-chain kernel that follows every assembly (k_factor_solve / k_factor_full) instead of by a memset node in front of every row pass
+  int* i8_vbad;
+  unsigned long long* i8_dmax;
   long long *iter, *accepted, *steps_done;
   // scratch
   double *wq, *uq, *PM, *u0, *q, *last, *Gq, *rv0, *rv2, *ljl_part, *qpart, *gpart;
@@ -1238,23 +1242,28 @@ __device__ __forceinline__ double cholsolve_lds(const double* L, int D, int lane
 // and wait for this load before anything else: 8 KB in flight per wavefront instead of 4)
 template <bool PK = false>
 __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict__ G, int D, int DP, int lane) {
+  // (PK: only the lower block triangle is kept, so only those columns are fetched: 20 of the 32 KB of a 64 x 64 matrix.  These kernels
+  //  are one wavefront per chain and, summed over a leapfrog step, bound by the bytes of the per-chain matrices they move.)
   const int l = lane < D ? lane : 0;
   int i = 0;
   for (; i + 16 <= D; i += 16) {
     double v[16];
+    const bool in = lane < rm_len<PK>(i);  // (i a multiple of 16: the sixteen rows belong to one block row)
+    if (in) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = G[(i + q) * DP + l];
+      for (int q = 0; q < 16; ++q) v[q] = G[(i + q) * DP + l];
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      if (lane < rm_len<PK>(i + q)) A[rm_row<PK>(i + q) + lane] = v[q];
+      for (int q = 0; q < 16; ++q) A[rm_row<PK>(i + q) + lane] = v[q];
+    }
   }
   for (; i + 8 <= D; i += 8) {
     double v[8];
+    if (lane < rm_len<PK>(i)) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = G[(i + q) * DP + l];
+      for (int q = 0; q < 8; ++q) v[q] = G[(i + q) * DP + l];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (lane < rm_len<PK>(i + q)) A[rm_row<PK>(i + q) + lane] = v[q];
+      for (int q = 0; q < 8; ++q) A[rm_row<PK>(i + q) + lane] = v[q];
+    }
   }
   for (; i < D; ++i)
     if (lane < rm_len<PK>(i)) A[rm_row<PK>(i) + lane] = G[i * DP + l];
@@ -1266,6 +1275,7 @@ __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict
 __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps) {
   __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (c == 0 && lane == 0 && ch.stale_list) *ch.stale_count = 0;  // (k_crestore has consumed the list; k_iter_end appends at the end of the step)
   if (ch.phase[c] != 1) return;
   load_mat_lds<true>(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
   const double rdiag = (lane < D) ? 1.0 / A[rm_row<true>(lane) + lane] : 1.0;
@@ -1282,7 +1292,9 @@ template <int NB>
 __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, double eps) {
   __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (c == 0 && lane == 0 && ch.i8_dmax) *ch.i8_dmax = 0ull;
   if (ch.phase[c] != 1) return;
+  if (lane == 0 && ch.i8_vbad) ch.i8_vbad[c] = 0;
   load_mat_lds<true>(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
   double rdiag;
   const int bad = chol_lds_blk<NB, true>(A, D, lane, rdiag);
@@ -1433,16 +1445,18 @@ __global__ __launch_bounds__(64) void k_factor_full(DevData dd, Chains ch, int n
   constexpr int DPc = 16 * NB;
   const int D = dd.D, DP = dd.DP;
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (c == 0 && lane == 0 && ch.i8_dmax) *ch.i8_dmax = 0ull;
   if (ch.phase[c] != 1) return;
+  if (lane == 0 && ch.i8_vbad) ch.i8_vbad[c] = 0;
   load_mat_lds<true>(A, ch.Gq + (size_t)c * DP * DP, D, DP, lane);
   double rdiag;
   const int bad = chol_lds_blk<NB, true>(A, D, lane, rdiag);
   // half log det = sum log diag(L) = -sum log(1/L_jj)   (rmhmc.py:171,175)
   const double hld = -wave_sum((lane < D) ? log(rdiag) : 0.0);
-  // store L (lower, zeros above)
+  // store L (lower; the entries above the diagonal are zero since the allocation and never written, here or by copy_rec)
   double* __restrict__ Lg = ch.trj.L + (size_t)c * DP * DP;
   for (int i = 0; i < D; ++i)
-    if (lane < D) Lg[i * DP + lane] = (lane <= i) ? A[rm_row<true>(i) + lane] : 0.0;
+    if (lane <= i) Lg[i * DP + lane] = A[rm_row<true>(i) + lane];
   __builtin_amdgcn_wave_barrier();
   spd_inverse_lds<NB, true>(A, D, lane, rdiag);
   double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
@@ -1548,9 +1562,13 @@ struct IterParams {
   int* done_count;
   const int* orig;        // work-sorted layout of the bulk sampler (rmhmc_hip.hip, sample_core): the chain at position c is chain orig[c] of the
                           // caller's order - its Philox key and its block of `samples` - or nullptr: position = chain
+  int lower_L;            // the records' L is a lower factor with an all-zero upper triangle (generic D <= 64 kernels): copy_rec moves the
+                          // lower part only
 };
 
-__device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, int D, int DP, int lane) {
+// lowerL: L holds a lower Cholesky factor whose upper triangle is zero in every record (the generic path, D <= 64): only the columns up
+// to the diagonal are moved
+__device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, int D, int DP, int lane, bool lowerL = false) {
   const size_t o = (size_t)c * DP;
   for (int d = lane; d < D; d += 64) {
     dst.w[o + d] = src.w[o + d];
@@ -1563,12 +1581,15 @@ __device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, 
     for (; i + 8 <= D; i += 8) {  // eight rows of both matrices in flight (the copy is latency bound: one wavefront per chain)
       double a[8], b[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { a[q] = src.L[m + (i + q) * DP + d]; b[q] = src.Ginv[m + (i + q) * DP + d]; }
+      for (int q = 0; q < 8; ++q) { a[q] = lowerL && d > i + 7 ? 0.0 : src.L[m + (i + q) * DP + d]; b[q] = src.Ginv[m + (i + q) * DP + d]; }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { dst.L[m + (i + q) * DP + d] = a[q]; dst.Ginv[m + (i + q) * DP + d] = b[q]; }
+      for (int q = 0; q < 8; ++q) {
+        if (!(lowerL && d > i + 7)) dst.L[m + (i + q) * DP + d] = a[q];   // (a lower factor: zero above the diagonal on both sides, always)
+        dst.Ginv[m + (i + q) * DP + d] = b[q];
+      }
     }
     for (; i < D; ++i) {
-      dst.L[m + i * DP + d] = src.L[m + i * DP + d];
+      if (!(lowerL && d > i)) dst.L[m + i * DP + d] = src.L[m + i * DP + d];
       dst.Ginv[m + i * DP + d] = src.Ginv[m + i * DP + d];
     }
   }
@@ -1622,7 +1643,7 @@ __device__ __forceinline__ void iter_begin_dev(int D, int DP, const Chains& ch, 
   // trajectory starts from the cached record of the current point (wNew = w.copy(), rmhmc.py:47).  After an ACCEPTED proposal the two
   // records are already identical (k_iter_end has just copied trj to cur), so the 2 x 64 KB copy is only made after a rejection - the
   // same per-chain flag that tells k_mompass the c tiles are not those of trj.w - and on paths that do not keep the flag (it stays 1).
-  if (!ch.cstale || ch.cstale[c]) copy_rec(ch.trj, ch.cur, c, D, DP, lane);
+  if (!ch.cstale || ch.cstale[c]) copy_rec(ch.trj, ch.cur, c, D, DP, lane, ip.lower_L != 0);
   const long long oc = ip.orig ? ip.orig[c] : c;
   // draws: z ~ randn(1,D), u_len ~ rand(), g_dir ~ randn()   (rmhmc.py:80,89,90)
   draw_normals(ip, c, it, D, lane, zs, oc);
@@ -1718,7 +1739,7 @@ __device__ __forceinline__ void iter_end_dev(int D, int DP, const Chains& ch, co
     rng_block(ip.seed, (unsigned long long)(ip.chain_offset + oc), (uint32_t)it, 0x40000000u, U0, u_acc);
   }
   const bool accept = (ratio > 0.0) || (ratio > log(u_acc));  // rmhmc.py:181
-  if (accept) copy_rec(ch.cur, ch.trj, c, D, DP, lane);
+  if (accept) copy_rec(ch.cur, ch.trj, c, D, DP, lane, ip.lower_L != 0);
   __builtin_amdgcn_wave_barrier();  // (a lane reads back only what it wrote itself)
   if (ip.samples && it >= ip.burn_in && it - ip.burn_in < ip.S)
     for (int d = lane; d < D; d += 64)

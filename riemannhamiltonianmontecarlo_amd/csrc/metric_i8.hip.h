@@ -361,7 +361,7 @@ constexpr int i8_lds_bytes() { return i8_nbuf<S, WN, TN>() * S * (I8_BM + 32 * T
 
 // probe / unit-test form (tools/i8_gemm_probe.hip): C[row][col] = sum_g acc_g 2^(-8g)
 template <int S, int WN, int TN, int PIN>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN >= 2 ? WN / 2 : 1, WN >= 2 ? WN / 2 : 1))) void k_gemm_i8_probe(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN >= 2 ? WN / 2 : 1, WN >= 4 ? WN / 2 : 2))) void k_gemm_i8_probe(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int nks,
                                                             int nC, int NP, double* __restrict__ C) {
   int cb, pb;
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, NPp / (32 * TN * WN), cb, pb)) return;

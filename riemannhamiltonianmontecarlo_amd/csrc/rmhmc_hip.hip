@@ -271,11 +271,10 @@ void launch_rowpass(rmhmc_ctx* ctx, Group& g, const double* w, double* out0, dou
     }
     dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
     if (ctx->i8 && MODE != RP_G) {  // int8 metric path: v goes out as byte slices (no fp64 row vector, no k_vsplit)
-      (void)hipMemsetAsync(g.vbad, 0, sizeof(int) * (size_t)g.nCp, st);
+      // (vbad and dmax are clear: the factor kernel behind the previous assembly has reset them, Chains::i8_vbad / i8_dmax)
       const VSlice vs{g.Vs, g.vbad, ctx->i8_nks, g.nCp, ctx->i8S, g.vexp, ctx->d_cmin, ctx->d_cmax};
       // (with c tiles nobody reads a natural-layout c on this path: k_mompass and k_trvec take the tiles)
       if (MODE != RP_G && delta) {
-        (void)hipMemsetAsync(g.dmax, 0, sizeof(unsigned long long), st);
         VSlice vd = vs;
         vd.vexp_d = g.vexp_d; vd.rebase = g.rebase; vd.dmax = g.dmax; vd.force_rebase = (int)ctx->opt.i8_force_rebase;
         if (MODE == RP_F) {
@@ -619,7 +618,7 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
         dim3 grid((unsigned)std::min((g.n + 63) / 64, 32), (unsigned)rsplit);
         NB_SWITCH(ctx, hipLaunchKernelGGL((k_crestore<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.w, g.ctile, g.ch.cstale,
                                           g.ch.stale_list, g.ch.stale_count));
-        (void)hipMemsetAsync(g.ch.stale_count, 0, sizeof(int), st);
+        // (the count is reset by k_pos_first, later in the step)
       });
     });
   // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
@@ -694,6 +693,7 @@ IterParams iter_params(rmhmc_ctx* ctx, const Group& g, const IterBase& b) {
     ip.z_in = ctx->d_z + (size_t)g.off * ctx->D; ip.ulen_in = ctx->d_ulen + g.off; ip.gdir_in = ctx->d_gdir + g.off; ip.uacc_in = ctx->d_uacc + g.off;
   }
   ip.done_count = b.count_done ? ctx->d_done : nullptr;
+  ip.lower_L = (!ctx->big && !ctx->medium && !ctx->fused && ctx->sampler == 0) ? 1 : 0;  // (k_factor_full is the only writer of trj.L there)
   return ip;
 }
 
@@ -1018,6 +1018,7 @@ int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, 
         RC(dalloc(ctx, &g.vbad, (size_t)g.nCp));
         RC(dalloc(ctx, &g.vexp, (size_t)g.nCp));
         RC(dalloc(ctx, &g.vexp_d, (size_t)g.nCp)); RC(dalloc(ctx, &g.rebase, (size_t)g.nCp)); RC(dalloc(ctx, &g.dmax, (size_t)1));
+        if (!ctx->big) { g.ch.i8_vbad = g.vbad; g.ch.i8_dmax = g.dmax; }
         if (ctx->big && ctx->opt.i8_delta && S == 6) RC(dalloc(ctx, &g.Gbase, (size_t)g.n * ctx->DP * ctx->DP));
         RC(dalloc(ctx, &g.Qs, (size_t)S * ctx->i8_nkp * g.nCp * 32));
         RC(dalloc(ctx, &g.qscale, (size_t)g.nCp));

@@ -121,6 +121,13 @@ int main(int argc, char** argv) {
       run_case<4, 4, 1, 1>(8192, 10000, 2080, false, 8);
       return 0;
     }
+    if (S == 42) {  // 4 slices: two 4-wave workgroups per CU (128 x 64 tiles, 72 KB of LDS each) against one 8-wave workgroup (128 x 128)
+      run_case<4, 2, 1, 1>(300, 300, 1000, true, 0);
+      run_case<4, 2, 1, 1>(8192, 2048, 10000, false, 8);
+      run_case<4, 4, 1, 1>(8192, 2048, 10000, false, 8);
+      run_case<4, 2, 1, 0>(8192, 2048, 10000, false, 8);
+      return 0;
+    }
     if (S == 5) run_case<5, 4, 1>(8192, 2080, 10000, false, 3);
     if (S == 6) run_case<6, 2, 1>(8192, 2080, 10000, false, 3);
     return 0;
