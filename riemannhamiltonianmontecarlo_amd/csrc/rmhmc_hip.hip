@@ -222,10 +222,7 @@ void flow_tick(rmhmc_ctx* ctx, long long steps = 1) {
   const long long stride = std::max<long long>(1, w / 4);
   if (ctx->flow_steps < stride) return;
   ctx->flow_steps = 0;
-  if (ctx->flow.empty()) {
-    ctx->flow.resize(4);
-    for (auto& e : ctx->flow) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-  }
+  if (ctx->flow.empty()) return;  // (created by rmhmc_create_opts)
   hipEvent_t e = ctx->flow[ctx->flow_ticks % 4];
   if (ctx->flow_ticks >= 4) (void)hipEventSynchronize(e);
   (void)hipEventRecord(e, ctx->stream);
@@ -774,7 +771,7 @@ void launch_fused(rmhmc_ctx* ctx, const IterBase& b, long long nsteps) {
       });
     }
     nsteps -= chunk;
-    flow_tick(ctx, ctx->opt.inflight);  // (one launch = up to 4096 steps: at most four launches queued)
+    if (nsteps > 0) flow_tick(ctx, ctx->opt.inflight);  // (one launch = up to 4096 steps: at most four launches queued ahead)
   }
 }
 
@@ -928,6 +925,8 @@ int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, 
   int rc = RMHMC_OK;
   auto body = [&]() -> int {
     HIPCK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->flow.resize(4);  // flow control events (flow_tick)
+    for (auto& e : ctx->flow) { e = nullptr; HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
     const size_t n = n_chains, DP = ctx->DP, Mp = ctx->Mp;
     double *Xr, *Xt, *t;
     RC(dalloc(ctx, &Xr, Mp * DP)); RC(dalloc(ctx, &Xt, DP * Mp)); RC(dalloc(ctx, &t, Mp));
@@ -1130,7 +1129,7 @@ void rmhmc_destroy(rmhmc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (auto& e : ctx->flow) (void)hipEventDestroy(e);
+  for (auto& e : ctx->flow) if (e) (void)hipEventDestroy(e);
   for (auto& kv : ctx->events) for (auto& e : kv.second) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (void* p : ctx->allocs) (void)hipFree(p);
