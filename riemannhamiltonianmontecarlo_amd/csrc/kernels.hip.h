@@ -792,9 +792,15 @@ __global__ __launch_bounds__(256) void k_assemble_f32(DevData dd, int n_chains, 
 //         for the wavefronts of k_mompass<.., 3> that hold a chain whose tiles are stale)
 //   CM 2  c loaded: no F product, no exp                             (the other K-1 iterations - same w -, and the pass of the point
 //         evaluation rmhmc.py:158-161, whose row pass k_rowpass<RP_F> has just stored c for the same w in the same layout)
-template <int NB, int CM>
+//   TRV   (CM 2, the pass of the point evaluation on the int8 path): the trace term's product tr_d = sum_n c_n h_n x_nd (rmhmc.py:148-156 through
+//         the leverages h the int8 GEMM has left in R) rides along - the same X' R form over the same rows and the same c tiles, so the
+//         operands and the tiles are read once for both products (it used to be a kernel of its own, k_trvec: 1.3 GB of R and c tiles per
+//         launch, 0.36 ms).  u then lives in LDS to make room for the second accumulator set.
+template <int NB, int CM, bool TRV = false>
 __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, int nsplit, const double* __restrict__ wq,
-                                             const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile) {
+                                             const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile,
+                                             const double* __restrict__ R = nullptr, double* __restrict__ trpart = nullptr) {
+  static_assert(!TRV || CM == 2, "the trace product rides on the pass that loads its c tiles");
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
   const int lane = threadIdx.x & 63;
@@ -808,6 +814,18 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
   for (int kk = 0; kk < KK; ++kk) {
     if (CM != 2) Wb[kk] = wq[(size_t)cj * DP + 4 * kk + rr];
     Ub[kk] = uq[(size_t)cj * DP + 4 * kk + rr];
+  }
+  __shared__ double s_u[TRV ? 4 * KK * 64 : 1];  // (TRV: the lane's own u values, written and read by the same lane: no barrier)
+  double* const my_u = s_u + (TRV ? ((threadIdx.x >> 6) * KK) * 64 + lane : 0);
+  if constexpr (TRV) {
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) my_u[kk * 64] = Ub[kk];
+  }
+  const double* __restrict__ rp = TRV ? R + (size_t)cj * dd.Mp + 8 * rr : nullptr;  // the lane's eight h values of a block: 64 contiguous bytes
+  d4 T[TRV ? NB : 1];
+  if constexpr (TRV) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) T[I] = (d4){0.0, 0.0, 0.0, 0.0};
   }
   // 32-row blocks of two interleaved 16-row tiles A / B, exactly as in k_rowpass (whose c tiles CM = 2 reads): lane (rr, ci) holds data
   // rows n0 + 8 rr + 2 r (A) and n0 + 8 rr + 2 r + 1 (B); one 16-byte load per lane brings the F / S operands of both tiles.
@@ -854,10 +872,13 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
         FA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, Wb[kk], FA, 0, 0, 0);
         FB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, Wb[kk], FB, 0, 0, 0);
       }
-      SA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, Ub[kk], SA, 0, 0, 0);
-      SB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, Ub[kk], SB, 0, 0, 0);
+      const double uk = TRV ? my_u[kk * 64] : Ub[kk];
+      SA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, uk, SA, 0, 0, 0);
+      SB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, uk, SB, 0, 0, 0);
     }
     d4 cA = ccA, cB = ccB;
+    d4 h0 = (d4){0.0, 0.0, 0.0, 0.0}, h1 = h0;
+    if constexpr (TRV) { h0 = *(const d4*)(rp + n0); h1 = *(const d4*)(rp + n0 + 4); }  // rows nl .. nl+3, nl+4 .. nl+7
     __builtin_amdgcn_sched_barrier(0);
     // (with the exp of c in the pass - CM 0 / 1 - the Q operands of a tile are requested just before its c, to stay within 256 registers)
 #pragma unroll
@@ -879,6 +900,11 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
       const double RA = cA[r] * SA[r] * SA[r];
 #pragma unroll
       for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[r][I], RA, Q[I], 0, 0, 0);
+      if constexpr (TRV) {
+        const double TA = cA[r] * (r < 2 ? h0[2 * r] : h1[2 * r - 4]);  // tile A: rows nl + 2 r
+#pragma unroll
+        for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[r][I], TA, T[I], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (CM != 2) {
@@ -902,6 +928,11 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
       const double RB = cB[r] * SB[r] * SB[r];
 #pragma unroll
       for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], RB, Q[I], 0, 0, 0);
+      if constexpr (TRV) {
+        const double TB = cB[r] * (r < 2 ? h0[2 * r + 1] : h1[2 * r - 3]);  // tile B: rows nl + 2 r + 1
+#pragma unroll
+        for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], TB, T[I], 0, 0, 0);
+      }
     }
   }
   if (c0 + ci < n_chains) {
@@ -913,11 +944,26 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
         const int d = NB * (rr + 4 * r) + I;
         if (d < dd.D) out[d] = Q[I][r];
       }
+    if constexpr (TRV) {  // (the layout k_trvec writes: summed over the row splits by k_reduce_tr)
+      double* __restrict__ tout = trpart + ((size_t)split * n_chains + c0 + ci) * DP;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = NB * (rr + 4 * r) + I;
+          if (d < dd.D) tout[d] = T[I][r];
+        }
+    }
   }
 }
 //   CM 3  per wavefront: CM 2 when the c tiles of all its 16 chains are those of w (Chains::cstale), CM 1 otherwise.  The first momentum
 //         iteration of a step: the evaluation that ended the previous step left the tiles of w behind for every chain that did not
 //         just reject a proposal (both routes produce the same bits: same operands, same operation order).
+template <int NB>
+__global__ __launch_bounds__(256, 2) void k_mompass_trv(DevData dd, int n_chains, int nsplit, const double* __restrict__ uq, double* __restrict__ qpart,
+                                                     d4* __restrict__ ctile, const double* __restrict__ R, double* __restrict__ trpart) {
+  mompass_body<NB, 2, true>(dd, n_chains, nsplit, nullptr, uq, qpart, ctile, R, trpart);
+}
 template <int NB, int CM>
 __global__ __launch_bounds__(256, 2) void k_mompass(DevData dd, int n_chains, int nsplit, const double* __restrict__ wq,
                                                  const double* __restrict__ uq, double* __restrict__ qpart, d4* __restrict__ ctile,

@@ -465,7 +465,18 @@ void launch_mompass(rmhmc_ctx* ctx, Group& g, const double* w, int cmode) {
   });
 }
 
-void launch_leverage(rmhmc_ctx* ctx, Group& g) {
+// The evaluation's momentum pass and the trace product are both X' R over the same rows and c tiles: on the generic int8 path with c tiles the
+// leverage GEMM runs first and k_mompass_trv does both products in one pass (fused_trace); otherwise k_trvec follows the GEMM.
+static bool fused_trace(const rmhmc_ctx* ctx, const Group& g) { return ctx->i8 && !ctx->big && g.ctile != nullptr && ctx->opt.ccache; }
+
+// part: 0 everything; 1 the leverage GEMM alone (h -> rv0); 2 the reduction of the trace partials alone
+void launch_leverage(rmhmc_ctx* ctx, Group& g, int part = 0) {
+  if (ctx->i8 && part == 2) {
+    launch(ctx, g, LIGHT, "small", [&](hipStream_t st) {
+      hipLaunchKernelGGL(k_reduce_tr, dim3((unsigned)g.n), dim3(64), 0, st, ctx->D, ctx->DP, g.ch, g.ch.gpart, g.nsplit);
+    });
+    return;
+  }
   if (ctx->i8) {  // h_n as the transposed sliced GEMM, then tr = X' (c .* h) on the fp64 matrix cores
     launch(ctx, g, HEAVY, "qsplit", [&](hipStream_t st) { I8_SWITCH(ctx, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 0))); });
     // The leverages h_n = x_n' G^-1 x_n enter the trace term only, which steers the momentum and appears in no Hamiltonian: like the metric
@@ -473,6 +484,7 @@ void launch_leverage(rmhmc_ctx* ctx, Group& g) {
     // instead of 21; h to ~3e-12 norm-wise, theta / p after a step move by < 1e-11; RMHMC_FLAG_INT8_INNER_FULL: all S)
     const int suse = (ctx->i8_inner_drop && ctx->i8S == 6) ? 5 : ctx->i8S;
     launch(ctx, g, HEAVY, "leverage_i8", [&](hipStream_t st) { I8_SWITCH_S(suse, (launch_leverage_i8_t<S_, WN_, TN_>(ctx, g, st, 1))); });
+    if (part == 1) return;
     launch(ctx, g, HEAVY, "trvec", [&](hipStream_t st) {
       if (ctx->big) {  // rv0 holds h (one "pair" plane), the large-D trace kernel multiplies by c itself
         dim3 grid((unsigned)((g.n + 15) / 16), g.nsplit);
@@ -562,8 +574,19 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, int
     ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
     return;
   }
-  ph.push_back([ctx](Group& g) { launch_mompass(ctx, g, g.ch.trj.w, 2); });  // (the row pass above has just stored c for trj.w)
-  ph.push_back([ctx](Group& g) { launch_leverage(ctx, g); });
+  ph.push_back([ctx](Group& g) {
+    if (fused_trace(ctx, g)) {  // leverage GEMM first, then ONE pass for the quadratic term and the trace term
+      launch_leverage(ctx, g, 1);
+      launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
+        dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
+        NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass_trv<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.uq, g.ch.qpart, g.ctile, g.ch.rv0, g.ch.gpart));
+      });
+      launch_leverage(ctx, g, 2);
+    } else {
+      launch_mompass(ctx, g, g.ch.trj.w, 2);  // (the row pass above has just stored c for trj.w)
+      launch_leverage(ctx, g);
+    }
+  });
   ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
 }
 
