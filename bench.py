@@ -110,6 +110,22 @@ def cpu_baseline(XX, t, flags, L, eps, K, budget_s=12.0, literal_budget_s=10.0):
                                                        "so it is FASTER than rmhmc.py's interpreter loop and the GPU/CPU ratio it gives is conservative",
                                       "sample": "%d chains x 1 leapfrog step incl. the set-up block (rmhmc.py:50-77), literal "
                                                 "tensor-forming C restatement of rmhmc.py, %.1f s" % (cores, dtl)}
+    # ... and the same literal algorithm in NumPy (oracle/rmhmc_numpy.py, pinned to the golden tapes like the C oracle): what north_star calls
+    # "the reference NumPy path".  One chain, as the reference runs; NumPy's BLAS uses the host cores it finds.
+    if literal_budget_s > 0 and D <= 64:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import rmhmc_numpy as rn
+        tt = np.ascontiguousarray(t, dtype=np.float64).ravel()
+        pt = rn.Point(XX, tt, np.full(D, 1e-3))                      # the set-up block (untimed: a step's own block is timed below)
+        pn = np.random.RandomState(0).randn(D)
+        t0 = time.perf_counter(); nst = 0
+        while nst < 1 or (time.perf_counter() - t0 < literal_budget_s / 3 and nst < 50):
+            pt, pn = rn.leapfrog(XX, tt, pt, pn, eps, 1.0, K, guards=False)
+            nst += 1
+        dtn = time.perf_counter() - t0
+        out["reference_numpy"] = {"value": nst / dtn, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+                                  "sample": "1 chain x %d leapfrog steps, NumPy restatement of rmhmc.py's literal O(M D^3) algorithm "
+                                            "(einsum tensor, LU inv / solve), %.1f s" % (nst, dtn)}
     return out
 
 
