@@ -141,7 +141,8 @@ __device__ __forceinline__ void wait_lgkm(i4v& a, i4v& b) {
 #endif
 
 // I8_ABLATE (tools/i8_gemm_probe.hip only; the library never defines it): bit 0 no LDS-DMA loads, bit 1 no fragment reads (the
-// fragments of the first stage are kept), bit 2 no barriers.  Timing ablations: the results are meaningless.
+// fragments of the first stage are kept), bit 2 no barriers, bit 3 LDS-DMA loads for the first four stages of a tile only (the products
+// then run on real bytes without a feed).  Timing ablations: the results are meaningless.
 #ifndef I8_ABLATE
 #define I8_ABLATE 0
 #endif
@@ -216,6 +217,7 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   static_assert(NBUF == 3 || ALLON, "the deeper ring relies on the unconditional issue");
   auto gl1 = [&](int ks, int buf, int s) {  // slice s of stage ks
     if (I8_ABLATE & 1) return;
+    if ((I8_ABLATE & 8) && ks >= 4) return;  // (bit 3: only the first stages of a tile are fetched: real bytes in LDS, no feed afterwards)
 #pragma unroll
     for (int k = 0; k < NU; ++k)
       if (ALLON || on[k])
