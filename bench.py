@@ -41,6 +41,9 @@ HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md (spec; 6.3e12 achievable, 5.
 INT8_MFMA_PEAK = 5.0e15   # op/s dense int8 matrix (2x the bf16 rate, MI355X_MICROARCH.md)
 INT8_MFMA_STREAM = 3.39e15  # op/s a bare v_mfma_i32_32x32x32_i8 stream sustains on random bytes with two waves per SIMD (2.89e15 with one; 5.04e15
                             # on zeros: the clock is given back under load; profiles/r02_i8_stream_probe.txt)
+INT8_FEED_FREE_REAL = 2.84e15  # op/s of the library's own tile on the REAL operand planes of config 3 when nothing is staged after the first stages
+                               # and no fragment is re-read (I8_ABLATE timing builds, profiles/r03_i8_real_ceiling.txt: 2.8-2.9e15 on the box that ran
+                               # the product at 2.48e15)
 FP64_MFMA_PEAK = 78.6e12  # flop/s dense fp64 matrix (spec); tools/mfma_probe measures 75.1e12
 
 WORKLOADS = {
@@ -348,6 +351,9 @@ def main():
                     "traffic": None, "avg_launch_ms": i_avg * 1e3, "launches": i_n,
                     "measured_mfma_stream_peak": INT8_MFMA_STREAM / 1e12,
                     "frac_of_measured_mfma_stream": ops / i_avg / INT8_MFMA_STREAM,
+                    "feed_free_rate_on_real_bytes": INT8_FEED_FREE_REAL / 1e12,
+                    "feed_free_note": "profiles/r03_i8_real_ceiling.txt: the same tile on the same bytes without LDS-DMA feed and fragment re-reads "
+                                      "sustains 2.8-2.9 POP/s (the chip gives the clock back under load); the product reached 0.83-0.87 of that on the same box",
                     "fp64_equivalent_tflops": 2.0 * n * M * NP / i_avg / 1e12,
                     "fp64_equivalent_frac_of_fp64_mfma_peak": 2.0 * n * M * NP / i_avg / FP64_MFMA_PEAK,
                     "vsplit_avg_launch_ms": kt["vsplit"][0] / max(1, kt["vsplit"][1]) * 1e3,
