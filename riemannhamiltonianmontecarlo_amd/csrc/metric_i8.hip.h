@@ -260,7 +260,12 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   int cur = 0;
   i4v fb[S][TN], fa[2][2];
   for (int ks = 0; ks < nks; ++ks) {
-    const int nxt = cur == NBUF - 1 ? 0 : cur + 1, wr = cur == 0 ? NBUF - 1 : cur - 1;  // wr: the buffer of stage ks - 1, free since the last barrier
+    // wr: the buffer of stage ks - 1, free since the last barrier.  (Written as additions and compares: `cur == 0 ? NBUF - 1 : cur - 1` made
+    // the compiler compute it on the VALU and read it back - v_sub_co_u32 / v_readfirstlane in front of every stage's m0 set-up, +5 % on the
+    // S = 5 launches of config 5.)
+    const int nxt = cur + 1 >= NBUF ? 0 : cur + 1;
+    int wr = cur + (NBUF - 1);
+    if (wr >= NBUF) wr -= NBUF;
     const bool spread = I8_DSPREAD && (WN != 4 || work);  // (waves that skip their MFMAs issue their loads at the top)
     const int kpre = ALLON ? min(ks + PD, nks - 1) : ks + PD;  // stage to prefetch (ALLON: clamped, always issued)
     if (!spread && (ALLON || ks + PD < nks)) gl(kpre, wr);
