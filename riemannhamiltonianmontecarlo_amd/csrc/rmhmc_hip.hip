@@ -330,7 +330,7 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
     return;
   }
   // Ragged last pair block (D = 64: 2080 pairs = 16 blocks of 128 + 32): once the full blocks alone fill the chip, the rest goes to
-  // k_assemble_i8_tail (bit-identical results, see there).  RMHMC_I8_TAIL=0 / 1: never / whenever there is a ragged block.
+  // k_assemble_i8_tail (bit-identical results, see there).  option i8_tail = 0 / 1: never / whenever there is a ragged block.
   const int nPBfull = ctx->pairs.NP / (32 * TN * WN);
   const bool tail = WN == 4 && g.Tq && nPBfull < nPB && (ctx->opt.i8_tail == 1 || (ctx->opt.i8_tail < 0 && (long long)nCB * nPBfull >= 256));
   const int npb = tail ? nPBfull : nPB;
@@ -1436,7 +1436,7 @@ int rmhmc_transition(rmhmc_ctx* ctx, double* w, const double* z, const double* u
 
 // ---- bulk entry points --------------------------------------------------------------------------
 // The ~40 launches of one global step captured once into a hipGraph and replayed: the generic path is launch bound
-// for small batches (config 1: 0.5 ms per step of one chain, nearly all of it launch latency).  RMHMC_GRAPH=0 disables.
+// for small batches (config 1: 0.5 ms per step of one chain, nearly all of it launch latency).  Option graph = 0 disables.
 struct StepGraph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
