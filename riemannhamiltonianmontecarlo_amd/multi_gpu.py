@@ -75,6 +75,15 @@ def _replicate_data(XX, t, device):
     return np.ascontiguousarray(h[: N * D].reshape(N, D)), np.ascontiguousarray(h[N * D:])
 
 
+def nanmin_rows(ess):
+    """min over the dimensions of a (chains, D) ESS tensor ignoring NaN entries (a constant coordinate has no ESS); a chain whose ESS is NaN
+    in EVERY dimension (a constant or diverged chain) gets NaN - not +inf, which would read as a perfect chain in any sum or mean"""
+    import torch
+    m = torch.nan_to_num(ess, nan=float("inf")).amin(dim=1, keepdim=True)
+    m[torch.isinf(m)] = float("nan")
+    return m
+
+
 def sample_sharded(XX, t, n_chains, NumOfIterations=6000, BurnIn=1000, NumOfLeapFrogSteps=6, StepSize=0.5,
                    NumOfNewtonSteps=4, *, seed=0, compat=True, theta0=None, alpha=100.0, gather="samples", lib=None, options=None):
     """Run ``n_chains`` chains sharded over the ranks of the initialised process group.
@@ -118,9 +127,7 @@ def sample_sharded(XX, t, n_chains, NumOfIterations=6000, BurnIn=1000, NumOfLeap
                 st = ctx.sample_stats_dev(odev, NumOfIterations, BurnIn, NumOfLeapFrogSteps, StepSize, NumOfNewtonSteps, seed=seed,
                                           chain_offset=start, theta0=th)
                 acc, steps, secs = st["accepted"], st["leapfrog_steps"], st["seconds"]
-                ess = _t.nan_to_num(st["ess"], nan=float("inf")).amin(dim=1, keepdim=True)   # nanmin over the dimensions ...
-                ess[_t.isinf(ess)] = float("nan")                                           # ... NaN when there is no finite one
-                summ = _t.cat([st["mean"], st["var"], ess], dim=1)
+                summ = _t.cat([st["mean"], st["var"], nanmin_rows(st["ess"])], dim=1)
                 smp = None
     else:
         smp = _t.zeros((0, S, D), dtype=_t.float64, device=odev)

@@ -107,6 +107,25 @@ def test_bench_default_line_shape():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in out["cpu_baseline"], k
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["reference_algorithm"]["kind"] == "port"
+    assert out["cpu_baseline"]["reference_numpy"]["value"] > 0          # the NumPy restatement of the reference's literal algorithm
+    assert out["config"]["options"]["graph"] == 1 and out["config"]["options"]["inflight"] == 32
+
+
+def test_bench_checkpoint_resume_is_the_state_the_burn_in_leaves(tmp_path):
+    """tools/profile.sh starts every profiled pass from `bench.py --save-state`: the resumed run continues the chains the burn-in left
+    (rmhmc_chains_state is a complete checkpoint; a chain stopped in mid-trajectory replays that transition from its start, so the
+    counters after the same number of further global steps differ by at most that one transition per chain)."""
+    common = ["--steps", "6", "--warmup", "2", "--workload", "c2", "--chains", "256", "--burn-in-steps", "24", "--ess-iters", "0",
+              "--no-cpu-baseline", "--no-alternates"]
+    a = _run_bench(common)
+    ck = str(tmp_path / "ck.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common + ["--save-state", ck], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and os.path.exists(ck), r.stderr[-1000:]
+    b = _run_bench(common + ["--load-state", ck, "--no-graph"])
+    assert a["all_finite"] and b["all_finite"] and abs(a["acceptance_rate"] - b["acceptance_rate"]) < 0.05
+    assert b["config"]["options"]["graph"] == 0
 
 
 def test_device_resident_outputs_match_host_outputs(hip):

@@ -13,6 +13,14 @@ from conftest import GOLDEN, ORACLE_LIB, ROOT
 from riemannhamiltonianmontecarlo_amd.multi_gpu import shard_range
 
 
+def test_nanmin_rows_keeps_nan_for_a_chain_without_any_finite_ess():
+    import torch
+    from riemannhamiltonianmontecarlo_amd.multi_gpu import nanmin_rows
+    e = torch.tensor([[3.0, float("nan"), 2.0], [float("nan")] * 3, [5.0, 7.0, 6.0]], dtype=torch.float64)
+    m = nanmin_rows(e).ravel()
+    assert m[0] == 2.0 and torch.isnan(m[1]) and m[2] == 5.0
+
+
 def test_shard_range_partitions():
     for n, w in ((10, 4), (8192, 8), (3, 8), (65536, 8), (7, 1)):
         r = [shard_range(n, w, k) for k in range(w)]
