@@ -1318,14 +1318,23 @@ __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict
 
 // position fixed point, first iterate (rmhmc.py:113-122 with FixedIter = 0): G(Pw^0) = G(w) is the
 // factor already stored in the trajectory record, so u = u0 and Pw^1 = w + tau*eps*u0.
-__global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps) {
+// upd_nsplit > 0: the last momentum fixed-point update p = p + tau eps/2 (grad - tr/2 + q/2) (rmhmc.py:108,110; k_mom_update with final = 1)
+// is done here first, q summed from upd_nsplit row-split planes
+__global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps, int upd_nsplit = 0) {
   __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c == 0 && lane == 0 && ch.stale_list) *ch.stale_count = 0;  // (k_crestore has consumed the list; k_iter_end appends at the end of the step)
   if (ch.phase[c] != 1) return;
   load_mat_lds<true>(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
   const double rdiag = (lane < D) ? 1.0 / A[rm_row<true>(lane) + lane] : 1.0;
-  const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
+  double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
+  if (upd_nsplit > 0 && lane < D) {
+    const size_t o = (size_t)c * DP + lane;
+    double q = 0.0;
+    for (int sp = 0; sp < upd_nsplit; ++sp) q += ch.qpart[((size_t)sp * ch.n + c) * DP + lane];
+    pb = pb + (ch.tau[c] * eps * 0.5) * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
+    ch.p[o] = pb;
+  }
   const double u0 = cholsolve_lds<true>(A, D, lane, pb, rdiag);
   if (lane < D) {
     ch.u0[(size_t)c * DP + lane] = u0;
@@ -1334,8 +1343,10 @@ __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, doub
 }
 
 // position fixed point, iterate k>=1 (rmhmc.py:116-122): factor G(Pw^k), solve, update Pw.
+// last >= 0: this is the last position iterate - the iterate is accepted as the new w and the position guard applied here (what k_pos_final
+// does in a launch of its own, rmhmc.py:123-130); last = the guards flag
 template <int NB>
-__global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, double eps) {
+__global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, double eps, int last = -1) {
   __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c == 0 && lane == 0 && ch.i8_dmax) *ch.i8_dmax = 0ull;
@@ -1346,10 +1357,16 @@ __global__ __launch_bounds__(64) void k_factor_solve(int D, int DP, Chains ch, d
   const int bad = chol_lds_blk<NB, true>(A, D, lane, rdiag);
   const double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
   const double u = cholsolve_lds<true>(A, D, lane, pb, rdiag);
-  if (lane < D)
-    ch.wq[(size_t)c * DP + lane] =
-        ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * (eps * 0.5) * (ch.u0[(size_t)c * DP + lane] + u);
-  if (bad && lane == 0) ch.status[c] |= 1;  // RMHMC_ST_NOT_PD
+  double wn = 0.0;
+  if (lane < D) wn = ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * (eps * 0.5) * (ch.u0[(size_t)c * DP + lane] + u);
+  int st = bad ? 1 : 0;  // RMHMC_ST_NOT_PD
+  if (last >= 0) {  // (k_pos_final's arithmetic: sum of squares over the lanes, sqrt, w / (3 |w|))
+    const double nw = sqrt(wave_sum(wn * wn));
+    if (last && nw > 10.0) { wn /= nw * 3.0; st |= 8; }  // RMHMC_ST_GUARD_W
+    if (lane < D) ch.trj.w[(size_t)c * DP + lane] = wn;
+  }
+  if (lane < D) ch.wq[(size_t)c * DP + lane] = wn;
+  if (st && lane == 0) ch.status[c] |= st;
 }
 
 // The per-chain vector kernels below run one wavefront per chain and stride the lanes over the dimensions
@@ -1567,14 +1584,41 @@ __global__ __launch_bounds__(64) void k_mom_update(int D, int DP, Chains ch, dou
   }
 }
 
+// k_mom_update (final = 0) followed by k_ginv_matvec on the new PM, in one launch (D <= 64: lane = dimension; the same sums in the same order)
+__global__ __launch_bounds__(64) void k_mom_update_matvec(int D, int DP, Chains ch, double eps, int nsplit) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (ch.phase[c] != 1) return;
+  const size_t o = (size_t)c * DP + lane;
+  double pm = 0.0;
+  if (lane < D) {
+    double q = 0.0;
+    for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + lane];
+    pm = ch.p[o] + (ch.tau[c] * eps * 0.5) * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
+    ch.PM[o] = pm;
+  }
+  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  double u = 0.0;
+  for (int j = 0; j < D; ++j) {
+    const double gj = (lane < D) ? Gi[j * DP + lane] : 0.0;  // symmetric: row j read coalesced
+    u = fma(gj, rdlane(pm, j), u);
+  }
+  if (lane < D) ch.uq[o] = u;
+}
+
 // explicit momentum half step at the new point (rmhmc.py:163) + step bookkeeping
-__global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, double eps, int advance, int nsplit) {
+// trpart != null: the trace term is summed here from its row-split planes first (k_reduce_tr's sums, in a launch of its own otherwise)
+__global__ __launch_bounds__(64) void k_mom_final(int D, int DP, Chains ch, double eps, int advance, int nsplit, const double* __restrict__ trpart = nullptr) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 1) return;
   const double h = ch.tau[c] * eps * 0.5;
   int nonfinite = 0;
   for (int d = lane; d < D; d += 64) {
     const size_t o = (size_t)c * DP + d;
+    if (trpart) {
+      double s = 0.0;
+      for (int sp = 0; sp < nsplit; ++sp) s += trpart[((size_t)sp * ch.n + c) * DP + d];
+      ch.trj.tr[o] = s;
+    }
     double q = 0.0;
     for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + d];
     ch.last[o] = q;

@@ -580,14 +580,15 @@ void eval_point_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph, bool advance, int
       launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
         dim3 grid((unsigned)((g.n + 63) / 64), g.nsplit);
         NB_SWITCH(ctx, hipLaunchKernelGGL((k_mompass_trv<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.nsplit, g.ch.uq, g.ch.qpart, g.ctile, g.ch.rv0, g.ch.gpart));
-      });
-      launch_leverage(ctx, g, 2);
+      });  // (k_mom_final below sums the trace partials itself)
     } else {
       launch_mompass(ctx, g, g.ch.trj.w, 2);  // (the row pass above has just stored c for trj.w)
       launch_leverage(ctx, g);
     }
   });
-  ph.push_back([ctx, advance](Group& g) { SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit); });
+  ph.push_back([ctx, advance](Group& g) {
+    SMALL(ctx, g, "small", k_mom_final, ctx->D, ctx->DP, g.ch, ctx->eps, advance ? 1 : 0, g.nsplit, fused_trace(ctx, g) ? g.ch.gpart : (const double*)nullptr);
+  });
 }
 
 // one-launch step / evaluation / folded global step for small batches (medium_step.hip.h).  Data rows per thread stay in registers
@@ -641,11 +642,14 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
         // (the count is reset by k_pos_first, later in the step)
       });
     });
-  // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110)
+  // implicit momentum half step: K fixed-point iterations (rmhmc.py:102-110).  D <= 64: the update that ends an iteration and the G^-1 PM
+  // product that starts the next are one launch (k_mom_update_matvec), the last update is done by k_pos_first
+  const bool fuse = !ctx->big;
   for (int it = 0; it < K; ++it) {
-    ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, it == 0 ? g.ch.p : g.ch.PM); });
+    if (it == 0 || !fuse) ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, it == 0 ? g.ch.p : g.ch.PM); });
     ph.push_back([=](Group& g) { launch_mompass(ctx, g, g.ch.trj.w, it == 0 ? 1 : 2); });
-    ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_mom_update, D, DP, g.ch, eps, it == K - 1 ? 1 : 0, g.nsplit); });
+    if (!fuse) ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_mom_update, D, DP, g.ch, eps, it == K - 1 ? 1 : 0, g.nsplit); });
+    else if (it < K - 1) ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_mom_update_matvec, D, DP, g.ch, eps, g.nsplit); });
   }
   // implicit position step: K fixed-point iterations (rmhmc.py:113-123); the first one re-uses the
   // stored factor of G(w)
@@ -653,8 +657,9 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_ginv_matvec, D, DP, g.ch, g.ch.p); });
     ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_pos_first_big, D, DP, g.ch, eps); });
   } else {
-    ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_pos_first, D, DP, g.ch, eps); });
+    ph.push_back([=](Group& g) { SMALL(ctx, g, "factor", k_pos_first, D, DP, g.ch, eps, g.nsplit); });
   }
+  const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
   for (int it = 1; it < K; ++it) {
     ph.push_back([=](Group& g) { launch_rowpass<RP_V>(ctx, g, g.ch.wq, g.ch.rv0, nullptr, use_delta_inner(ctx, g, it)); });
     ph.push_back([=](Group& g) {
@@ -665,13 +670,12 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
       ph.push_back([=](Group& g) { BIG(ctx, g, "factor", k_chol_big<0>, ctx->dd, g.ch, ctx->nbk, ctx->d_Wd + (size_t)g.off * ctx->nbk * 4096, eps); });
     else
       ph.push_back([=](Group& g) {
-        launch(ctx, g, LIGHT, "factor", [&](hipStream_t st) {
-          NB_SWITCH(ctx, hipLaunchKernelGGL((k_factor_solve<NB_>), dim3((unsigned)g.n), dim3(64), 0, st, D, DP, g.ch, eps));
+        launch(ctx, g, LIGHT, "factor", [&](hipStream_t st) {  // (the last iterate: accepted as the new w, position guard, in the same launch)
+          NB_SWITCH(ctx, hipLaunchKernelGGL((k_factor_solve<NB_>), dim3((unsigned)g.n), dim3(64), 0, st, D, DP, g.ch, eps, it == K - 1 ? guards : -1));
         });
       });
   }
-  const int guards = (ctx->flags & RMHMC_FLAG_GUARDS) ? 1 : 0;
-  ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_pos_final, D, DP, g.ch, guards); });
+  if (ctx->big || K < 2) ph.push_back([=](Group& g) { SMALL(ctx, g, "small", k_pos_final, D, DP, g.ch, guards); });
   // explicit momentum half step at the new point (rmhmc.py:134-163)
   eval_point_phases(ctx, ph, true);
 }
