@@ -262,10 +262,17 @@ __device__ __forceinline__ void gemm_i8_tile(const int8_t* __restrict__ Vs, cons
   for (int ks = 0; ks < nks; ++ks) {
     // wr: the buffer of stage ks - 1, free since the last barrier.  (Written as additions and compares: `cur == 0 ? NBUF - 1 : cur - 1` made
     // the compiler compute it on the VALU and read it back - v_sub_co_u32 / v_readfirstlane in front of every stage's m0 set-up, +5 % on the
-    // S = 5 launches of config 5.)
+    // S = 5 launches of config 5.)  The four-buffer ring (S <= 4) keeps the other form: with it the workgroups of an XCD stay in step and
+    // every operand tile is fetched once per super-tile - rocprofv3 --pmc FETCH_SIZE 1 043 396 KiB on every launch at config 3 against
+    // 2 059 220 - 2 108 123 with the additions, 1.414 against 1.444 ms per launch (same box, tools/fetch_ab.sh).
     const int nxt = cur + 1 >= NBUF ? 0 : cur + 1;
-    int wr = cur + (NBUF - 1);
-    if (wr >= NBUF) wr -= NBUF;
+    int wr;
+    if constexpr (NBUF == 4) {
+      wr = cur == 0 ? NBUF - 1 : cur - 1;
+    } else {
+      wr = cur + (NBUF - 1);
+      if (wr >= NBUF) wr -= NBUF;
+    }
     const bool spread = I8_DSPREAD && (WN != 4 || work);  // (waves that skip their MFMAs issue their loads at the top)
     const int kpre = ALLON ? min(ks + PD, nks - 1) : ks + PD;  // stage to prefetch (ALLON: clamped, always issued)
     if (!spread && (ALLON || ks + PD < nks)) gl(kpre, wr);
