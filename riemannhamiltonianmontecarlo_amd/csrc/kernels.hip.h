@@ -128,6 +128,26 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint64_t chain, uint32_
 // of its chain.  k_mompass and k_trvec use the same assignment (the c tiles of k_rowpass<RP_F> are read by k_mompass<.., 2>).
 // ---------------------------------------------------------------------------------------------
 typedef double d2 __attribute__((ext_vector_type(2)));
+// Buffer loads (MUBUF, raw): address = descriptor base + an SGPR offset + a 32-bit lane offset, so the row passes keep ONE loop-invariant
+// lane offset per operand stream and advance a scalar - no 64-bit vector address arithmetic in the loops (the global_load form cost a
+// v_lshl_add_u64 per load: ~50 per 64 MFMAs in k_mompass).  No bounds (num_records 2^32 - 1): every offset stays below 4 GB of its base
+// (rmhmc_create checks Mp * DP * 8; per-wave bases for the c tiles and R).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t brsrc;
+__device__ __forceinline__ brsrc buf_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000); }
+__device__ __forceinline__ d2 buf_d2(brsrc r, unsigned voff, unsigned soff) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+__device__ __forceinline__ double buf_d1(brsrc r, unsigned voff, unsigned soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+__device__ __forceinline__ d4 buf_d4(brsrc r, unsigned voff, unsigned soff) {
+  const d2 a = buf_d2(r, voff, soff), b = buf_d2(r, voff + 16u, soff);
+  return (d4){a.x, a.y, b.x, b.y};
+}
+template <int N>
+__device__ __forceinline__ void buf_dn(brsrc r, unsigned voff, unsigned soff, double (&x)[N]) {  // N consecutive doubles
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) { const d2 a = buf_d2(r, voff + 8u * i, soff); x[i] = a.x; x[i + 1] = a.y; }
+  if (N & 1) x[N - 1] = buf_d1(r, voff + 8u * (N - 1), soff);
+}
 // Q[j] (j < S): byte r = balanced base-256 digit j (least significant first) of N_r = rint(v_r 2^(8S + vexp)), r = 0..3.
 template <int S>
 __device__ __forceinline__ void slice_digits(const d4& vv, double vscale, double vmagic, int vsh, int& bad, unsigned (&Q)[S]) {
@@ -804,7 +824,7 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
   constexpr int DP = 16 * NB;
   constexpr int KK = DP / 4;
   const int lane = threadIdx.x & 63;
-  const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const int c0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * 16;
   if (c0 >= n_chains) return;
   const int split = blockIdx.y;
   const int rr = lane >> 4, ci = lane & 15;
@@ -821,7 +841,8 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) my_u[kk * 64] = Ub[kk];
   }
-  const double* __restrict__ rp = TRV ? R + (size_t)cj * dd.Mp + 8 * rr : nullptr;  // the lane's eight h values of a block: 64 contiguous bytes
+  const brsrc rXt = buf_rsrc(dd.Xt), rXr = buf_rsrc(dd.Xr), rR = buf_rsrc(TRV ? R + (size_t)c0 * dd.Mp : nullptr);
+  const unsigned r_off = (unsigned)((cj - c0) * dd.Mp + 8 * rr) * 8u;  // the lane's eight h values of a block: 64 contiguous bytes
   d4 T[TRV ? NB : 1];
   if constexpr (TRV) {
 #pragma unroll
@@ -833,6 +854,9 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
   const int per = (nb32 + nsplit - 1) / nsplit;
   const int B0 = split * per, B1 = min(nb32, B0 + per);
   d4* __restrict__ ct = ctile + (size_t)(c0 >> 4) * nb16 * 64 + lane;
+  const brsrc rC = buf_rsrc(ctile + (size_t)(c0 >> 4) * nb16 * 64);
+  const unsigned c_off = (unsigned)lane * 32u;
+  auto load_c = [&](int t) { return buf_d4(rC, c_off, (unsigned)t * 2048u); };  // tile t of this chain group
   d4 Q[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) Q[I] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -846,12 +870,12 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
   auto load_a = [&](int B, int k0, int k1) {
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
-      if (kk >= k0 && kk < k1) A[kk] = *(const d2*)((const char*)(dd.Xt + (size_t)(4 * kk) * dd.Mp + (size_t)B * 32) + xt_off);
+      if (kk >= k0 && kk < k1) A[kk] = buf_d2(rXt, xt_off, (unsigned)(4 * kk * dd.Mp + B * 32) * 8u);
   };
-  auto xrow = [&](int n, int I) { return *(const double*)((const char*)(dd.Xr + (size_t)n * DP + I) + xr_off); };
+  auto xrow4 = [&](int n, double (&x)[NB]) { buf_dn<NB>(rXr, xr_off, (unsigned)(n * DP) * 8u, x); };  // X[n + 8rr + ..][NB ci .. NB ci + NB - 1]
   if (B0 < B1) {
     load_a(B0, 0, KK);
-    if (CM == 2) { ccA = ct[(size_t)(2 * B0) * 64]; ccB = ct[(size_t)(2 * B0 + 1) * 64]; }
+    if (CM == 2) { ccA = load_c(2 * B0); ccB = load_c(2 * B0 + 1); }
   }
   for (int B = B0; B < B1; ++B) {
     const int n0 = 32 * B;
@@ -860,9 +884,7 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
     double xa[4][NB], xb[4][NB];
     if (CM == 2) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int I = 0; I < NB; ++I) xa[r][I] = xrow(n0 + 2 * r, I);
+      for (int r = 0; r < 4; ++r) xrow4(n0 + 2 * r, xa[r]);
       __builtin_amdgcn_sched_barrier(0);
     }
     d4 FA = (d4){0.0, 0.0, 0.0, 0.0}, FB = FA, SA = FA, SB = FA;
@@ -878,16 +900,14 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
     }
     d4 cA = ccA, cB = ccB;
     d4 h0 = (d4){0.0, 0.0, 0.0, 0.0}, h1 = h0;
-    if constexpr (TRV) { h0 = *(const d4*)(rp + n0); h1 = *(const d4*)(rp + n0 + 4); }  // rows nl .. nl+3, nl+4 .. nl+7
+    if constexpr (TRV) { h0 = buf_d4(rR, r_off, (unsigned)n0 * 8u); h1 = buf_d4(rR, r_off + 32u, (unsigned)n0 * 8u); }  // rows nl .. nl+3, nl+4 .. nl+7
     __builtin_amdgcn_sched_barrier(0);
     // (with the exp of c in the pass - CM 0 / 1 - the Q operands of a tile are requested just before its c, to stay within 256 registers)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int I = 0; I < NB; ++I) {
-        if (CM == 2) xb[r][I] = xrow(n0 + 2 * r + 1, I);
-        else xa[r][I] = xrow(n0 + 2 * r, I);
-      }
+    for (int r = 0; r < 4; ++r) {
+      if (CM == 2) xrow4(n0 + 2 * r + 1, xb[r]);
+      else xrow4(n0 + 2 * r, xa[r]);
+    }
     if (B + 1 < B1) load_a(B + 1, 0, KK / 2);  // (the other half once tile A's Q operands are used up: registers)
     __builtin_amdgcn_sched_barrier(0);
     if (CM != 2) {
@@ -909,13 +929,11 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
     __builtin_amdgcn_sched_barrier(0);
     if (CM != 2) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int I = 0; I < NB; ++I) xb[r][I] = xrow(n0 + 2 * r + 1, I);
+      for (int r = 0; r < 4; ++r) xrow4(n0 + 2 * r + 1, xb[r]);
     }
     if (B + 1 < B1) {
       load_a(B + 1, KK / 2, KK);
-      if (CM == 2) { ccA = ct[(size_t)(2 * B + 2) * 64]; ccB = ct[(size_t)(2 * B + 3) * 64]; }
+      if (CM == 2) { ccA = load_c(2 * B + 2); ccB = load_c(2 * B + 3); }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (CM != 2) {
