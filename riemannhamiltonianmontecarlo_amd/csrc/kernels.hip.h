@@ -415,8 +415,9 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
   const int B0 = split * per, B1 = min(nb32, B0 + per);
   // (wave-uniform base + one 32-bit per-lane byte offset: the loads take the scalar-base form, no 64-bit address registers per operand)
   const unsigned xt_off = (unsigned)(rr * dd.Mp + 2 * rm_perm16(ci)) * 8u;  // F operands: X[n0 + 2 perm(ci) + {0,1}][4kk+rr]
-  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + 2 * rm_perm16(ci);
   const unsigned xr_off = (unsigned)(8 * rr * DP + NB * ci) * 8u;           // gradient operands: X[n0 + 8rr + k][NB ci + I]
+  const double* __restrict__ xt_p = dd.Xt + (size_t)rr * dd.Mp + 2 * rm_perm16(ci);
+  const brsrc rXt = buf_rsrc(dd.Xt);
   double lj = 0.0;
   int bad = 0;
   d4 Gr[NB];
@@ -429,11 +430,17 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
       if (kk >= k0 && kk < k1) {
-        if (MODE == RP_V) A[kk] = *(const d2*)(xt_p + (size_t)(4 * kk) * dd.Mp + B * 32);  // (registers to spare; the 16 scalar bases would spill SGPRs)
+        // (buffer loads where they pay: the plain v pass 333 -> 321 us; the delta pass 439 -> 465 and RP_F 761 -> 781 with them, same box)
+        if (MODE == RP_V && !DELTA) A[kk] = buf_d2(rXt, xt_off, (unsigned)(4 * kk * dd.Mp + B * 32) * 8u);
+        else if (MODE == RP_V) A[kk] = *(const d2*)(xt_p + (size_t)(4 * kk) * dd.Mp + B * 32);  // (registers to spare; the 16 scalar bases would spill SGPRs)
         else A[kk] = *(const d2*)((const char*)(dd.Xt + (size_t)(4 * kk) * dd.Mp + (size_t)B * 32) + xt_off);
       }
   };
-  auto xrow = [&](int n, int I) { return *(const double*)((const char*)(dd.Xr + (size_t)n * DP + I) + xr_off); };
+  // (the gradient operands stay global loads: as buffer loads they cost RP_F sixteen more spilled registers)
+  auto xrow4 = [&](int n, double (&x)[NB]) {  // X[n + 8rr + ..][NB ci .. NB ci + NB - 1]
+#pragma unroll
+    for (int I = 0; I < NB; ++I) x[I] = *(const double*)((const char*)(dd.Xr + (size_t)n * DP + I) + xr_off);
+  };
   // element-wise part of one tile: F -> p, v, c (sigmoid4) and, for RP_F / RP_G, the terms of the log joint and of its gradient
   // (rmhmc.py:100,140,167-168); rows nl + 2 r + h.  log(1 + e^f) = max(f, 0) - log y with y = p (f >= 0) or 1 - p (f < 0) in [1/2, 1], so
   // the lane's share of the log joint is  sum (f t - max(f, 0)) + log(prod y):  one multiplication per row and one log per LJ_FLUSH
@@ -489,9 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
     d4 tA = (d4){0.0, 0.0, 0.0, 0.0}, tB = tA;
     if (MODE != RP_V) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int I = 0; I < NB; ++I) xa[r][I] = xrow(n0 + 2 * r, I);
+      for (int r = 0; r < 4; ++r) xrow4(n0 + 2 * r, xa[r]);
       const d4 t0 = *(const d4*)(dd.t + nl), t1 = *(const d4*)(dd.t + nl + 4);
       tA = (d4){t0[0], t0[2], t1[0], t1[2]};
       tB = (d4){t0[1], t0[3], t1[1], t1[3]};
@@ -508,9 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
     __builtin_amdgcn_sched_barrier(0);
     if (MODE != RP_V) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int I = 0; I < NB; ++I) xb[r][I] = xrow(n0 + 2 * r + 1, I);
+      for (int r = 0; r < 4; ++r) xrow4(n0 + 2 * r + 1, xb[r]);
       if (B + 1 < B1) load_a(B + 1, 0, KK / 2);
       __builtin_amdgcn_sched_barrier(0);
     }
