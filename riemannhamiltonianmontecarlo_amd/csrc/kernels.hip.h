@@ -479,6 +479,17 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
   const int Be = min(B1, Bc + LJ_FLUSH);
   for (int B = Bc; B < Be; ++B) {
     const int n0 = 32 * B, nl = n0 + 8 * rr;  // the lane's eight data rows nl .. nl+7
+    // DELTA, v pass: the stored digits of this block (six 8-byte loads per lane) are requested in front of the F products instead of where the
+    // slicing code needs them (the gradient variant has no registers to hold them that long)
+    constexpr bool PREQ = DELTA && I8 && MODE == RP_V;
+    uint2 oq[PREQ ? 6 : 1];
+    if constexpr (PREQ) {
+      const int8_t* vq = vs.Vs + ((size_t)min(B, vs.nks - 1) * vs.nCp + cj) * 32 + 8 * rr;
+      const size_t plane = (size_t)vs.nks * vs.nCp * 32;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) oq[j] = *(const uint2*)(vq + (size_t)(5 - j) * plane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // gradient operands of a tile are requested just before its element-wise work and land behind it; the two tiles are worked off
     // one after the other to keep the live registers of the exp / softplus code low
     double xa[4][NB], xb[4][NB];
@@ -490,9 +501,16 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
       else wk = Wb[kk];
       FA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, wk, FA, 0, 0, 0);
       FB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, wk, FB, 0, 0, 0);
+      // delta v pass: the operand pair is re-loaded with the next block's right behind the two products that read it (one load per MFMA pair
+      // instead of sixteen in a row after the products; the last block re-loads its own): 437 -> 405 us with the digit prefetch above.  The
+      // plain v pass (three wavefronts per SIMD) measured 1 % slower that way and keeps the burst; RP_F / RP_G: in halves behind the tiles' work
+      if (MODE == RP_V && DELTA) {
+        load_a(B + 1 < B1 ? B + 1 : B, kk, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == RP_V && B + 1 < B1) load_a(B + 1, 0, KK);  // (RP_F / RP_G: in halves behind the tiles' work, for the registers)
+    if (MODE == RP_V && !DELTA && B + 1 < B1) load_a(B + 1, 0, KK);
     d4 tA = (d4){0.0, 0.0, 0.0, 0.0}, tB = tA;
     if (MODE != RP_V) {
 #pragma unroll
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass(DevData dd, int n_chains, in
           unsigned OA[6], OB[6];
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            const uint2 q = *(const uint2*)(vp + (size_t)(5 - j) * plane);
+            const uint2 q = PREQ ? oq[j] : *(const uint2*)(vp + (size_t)(5 - j) * plane);
             OA[j] = __builtin_amdgcn_perm(q.y, q.x, 0x06040200u);
             OB[j] = __builtin_amdgcn_perm(q.y, q.x, 0x07050301u);
           }
@@ -876,9 +894,76 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
       if (kk >= k0 && kk < k1) A[kk] = buf_d2(rXt, xt_off, (unsigned)(4 * kk * dd.Mp + B * 32) * 8u);
   };
   auto xrow4 = [&](int n, double (&x)[NB]) { buf_dn<NB>(rXr, xr_off, (unsigned)(n * DP) * 8u, x); };  // X[n + 8rr + ..][NB ci .. NB ci + NB - 1]
+  if constexpr (CM == 2) {
+    // CM 2 (no element-wise work but the products c S^2): every operand register is re-loaded with the NEXT block's value right behind the
+    // matrix instruction that read it last - one or two loads after every two to four MFMAs, each with a whole block (64 MFMAs) to land -
+    // instead of bursts of 8 - 16 loads between the product groups: with the bursts the 36 loads of a block cost ~20 cycles of matrix
+    // pipe each (both wavefronts of a SIMD in their load phase together; ablation timings in profiles/r03_notes.txt).  The last block
+    // re-loads its own operands (no branch around the loads).  Same products in the same order as CM 0 / 1: the same bits.
+    double xa[4][NB], xb[4][NB];
+    d4 h0 = (d4){0.0, 0.0, 0.0, 0.0}, h1 = h0;
+    if (B0 < B1) {
+      load_a(B0, 0, KK);
+      ccA = load_c(2 * B0);
+      ccB = load_c(2 * B0 + 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xrow4(32 * B0 + 2 * r, xa[r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xrow4(32 * B0 + 2 * r + 1, xb[r]);
+    }
+    for (int B = B0; B < B1; ++B) {
+      const int Bn = B + 1 < B1 ? B + 1 : B, n1 = 32 * Bn;
+      d4 SA = (d4){0.0, 0.0, 0.0, 0.0}, SB = SA;
+      // (TRV: the leverages of THIS block, requested in front of its 32 S products - their registers are free during the Q / T products)
+      if constexpr (TRV) { h0 = buf_d4(rR, r_off, (unsigned)(32 * B) * 8u); h1 = buf_d4(rR, r_off + 32u, (unsigned)(32 * B) * 8u); }
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const double uk = TRV ? my_u[kk * 64] : Ub[kk];
+        SA = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].x, uk, SA, 0, 0, 0);
+        SB = __builtin_amdgcn_mfma_f64_16x16x4f64(A[kk].y, uk, SB, 0, 0, 0);
+        A[kk] = buf_d2(rXt, xt_off, (unsigned)(4 * kk * dd.Mp + Bn * 32) * 8u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      double RA[4], RB[4], TA[TRV ? 4 : 1], TB[TRV ? 4 : 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        RA[r] = ccA[r] * SA[r] * SA[r];
+        RB[r] = ccB[r] * SB[r] * SB[r];
+        if constexpr (TRV) {
+          TA[r] = ccA[r] * (r < 2 ? h0[2 * r] : h1[2 * r - 4]);      // tile A: rows nl + 2 r
+          TB[r] = ccB[r] * (r < 2 ? h0[2 * r + 1] : h1[2 * r - 3]);  // tile B: rows nl + 2 r + 1
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ccA = load_c(2 * Bn);
+      ccB = load_c(2 * Bn + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[r][I], RA[r], Q[I], 0, 0, 0);
+        if constexpr (TRV) {
+#pragma unroll
+          for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[r][I], TA[r], T[I], 0, 0, 0);
+        }
+        xrow4(n1 + 2 * r, xa[r]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Q[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], RB[r], Q[I], 0, 0, 0);
+        if constexpr (TRV) {
+#pragma unroll
+          for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], TB[r], T[I], 0, 0, 0);
+        }
+        xrow4(n1 + 2 * r + 1, xb[r]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
   if (B0 < B1) {
     load_a(B0, 0, KK);
-    if (CM == 2) { ccA = load_c(2 * B0); ccB = load_c(2 * B0 + 1); }
   }
   for (int B = B0; B < B1; ++B) {
     const int n0 = 32 * B;
@@ -955,6 +1040,7 @@ __device__ __forceinline__ void mompass_body(const DevData& dd, int n_chains, in
         for (int I = 0; I < NB; ++I) T[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[r][I], TB, T[I], 0, 0, 0);
       }
     }
+  }
   }
   if (c0 + ci < n_chains) {
     double* __restrict__ out = qpart + ((size_t)split * n_chains + c0 + ci) * DP;
