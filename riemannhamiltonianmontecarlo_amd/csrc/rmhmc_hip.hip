@@ -927,6 +927,10 @@ int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, 
   if (D > 256) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: D > 256 is not supported (64 < D <= 256 uses the blocked large-D path)");
   if (flags & RMHMC_FLAG_ORACLE_LITERAL) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: the literal variant exists only in the CPU oracle");
   if (M > (int64_t)1 << 30 || n_chains > (int64_t)1 << 30) return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: M or n_chains too large");
+  // (the row passes of the D <= 64 path address X, a chain group's c tiles and its leverages with 32-bit byte offsets from a buffer
+  //  descriptor's base: buf_rsrc in kernels.hip.h)
+  if (D <= 64 && (M + 63) / 64 * 64 * (int64_t)(16 * ((D + 15) / 16)) * 8 >= (int64_t)1 << 32)
+    return fail(nullptr, RMHMC_ERR_UNSUPPORTED, "rmhmc_create: the data matrix of the D <= 64 path must stay below 4 GB");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, RMHMC_ERR_NO_DEVICE, "rmhmc_create: no HIP device available (this library has no CPU fallback)");

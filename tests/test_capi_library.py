@@ -48,6 +48,15 @@ def test_no_gpu_fails_loudly(hip):
         RMHMC(X, t, NumOfIterations=4, BurnIn=1, verbose=False)
 
 
+def test_shape_limits_rejected_before_any_device_call(hip):
+    """rmhmc_create's shape checks need no GPU: D > 256, and a D <= 64 data matrix of 4 GB or more (32-bit offsets of the row passes)."""
+    for shape in ((100, 257, 1), ((1 << 23) + 1, 64, 1), (1 << 25, 16, 1)):
+        with pytest.raises(_capi.RmhmcError) as e:
+            hip.context(*shape)
+        assert e.value.code == -4, (shape, str(e.value))  # RMHMC_ERR_UNSUPPORTED
+    assert "4 GB" in str(e.value)
+
+
 def test_shim_argument_checks():
     X = np.zeros((5, 2)); t = np.zeros(5)
     with pytest.raises(ValueError):
