@@ -612,11 +612,10 @@ __device__ __forceinline__ bool I8Delta::skip() const {
 // (waves per SIMD stated explicitly: with 4 waves per workgroup the compiler otherwise budgets 256 registers and shuttles
 // accumulators through AGPR copies)
 template <int S, int WN, int TN>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
-                                                          int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
-                                                          const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
-                                                          size_t plane_stride, const int* __restrict__ vexp, int npb, I8Delta dl) {
-  if (dl.skip()) return;
+__device__ __forceinline__ void assemble_i8_body(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
+                                                 int ks0, int nk, int accumulate, const I8Pairs& pr, int n_chains, const int* __restrict__ phase,
+                                                 const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
+                                                 size_t plane_stride, const int* __restrict__ vexp, int npb, const I8Delta& dl) {
   int cb, pb;  // npb: pair blocks of this launch (all of them, or the full ones when k_assemble_i8_tail takes the ragged rest)
   if (!i8_tile_of_block(blockIdx.x, nCp / I8_BM, npb, cb, pb)) return;
   // data rows [32 ks0, 32 (ks0 + nk)): long data sets are summed in several launches so that the int32 accumulators cannot overflow.
@@ -665,6 +664,35 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
     if (ok) *gp = g;
   });
 }
+template <int S, int WN, int TN>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8(const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int nks_total,
+                                                          int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
+                                                          const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
+                                                          size_t plane_stride, const int* __restrict__ vexp, int npb, I8Delta dl) {
+  if (dl.skip()) return;
+  assemble_i8_body<S, WN, TN>(Vs, Zs, nCp, nks_total, ks0, nk, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, plane_stride, vexp, npb, dl);
+}
+// Delta assembly, ONE launch for whatever the difference needs (it used to be three - the 6-, 5- and 4-slice instantiations, two of which
+// looked at *dsel and returned: ~4.6 us each, twelve of them per leapfrog step with the tail kernels): the kernel reads the maximum the row
+// pass has left and runs the tile of that many slices on the planes seff - S' .. seff - 1 (seff = 6: every digit counts; seff = 5: an inner
+// iterate on five-slice accuracy, which needs 5 slices where the difference asks for 6 and 4 otherwise).  Same tile code, same planes,
+// same scale as the separate launches: bit-identical G.
+__device__ __forceinline__ int i8_delta_pick(const I8Delta& dl, int seff) {
+  const int need = i8_delta_slices(*dl.dsel);
+  return seff == 6 ? need : (need == 6 ? 5 : 4);
+}
+template <int WN, int TN>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2))) void k_assemble_i8_sel(const int8_t* __restrict__ Vs, size_t vplane, int seff, const int8_t* __restrict__ Zs, int nCp, int nks_total,
+                                                          int ks0, int nk, int accumulate, I8Pairs pr, int n_chains, const int* __restrict__ phase,
+                                                          const int* __restrict__ vbad, int DP, double inv_alpha, double* __restrict__ Gq,
+                                                          size_t plane_stride, const int* __restrict__ vexp, int npb, I8Delta dl) {
+  const int Sp = i8_delta_pick(dl, seff);
+  dl.cscale = __builtin_ldexp(1.0, -8 * (seff - Sp));
+  Vs += (size_t)(seff - Sp) * vplane;
+  if (Sp == 6) assemble_i8_body<6, WN, TN>(Vs, Zs, nCp, nks_total, ks0, nk, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, plane_stride, vexp, npb, dl);
+  else if (Sp == 5) assemble_i8_body<5, WN, TN>(Vs, Zs, nCp, nks_total, ks0, nk, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, plane_stride, vexp, npb, dl);
+  else assemble_i8_body<4, WN, TN>(Vs, Zs, nCp, nks_total, ks0, nk, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, plane_stride, vexp, npb, dl);
+}
 
 // The pairs beyond the last FULL block of 32 WN pairs (D = 64: 2080 = 16 x 128 + 32) as tiles of their own.  In the main launch
 // they made a 17th pair block per chain block whose workgroups, three wave columns idle, still took 0.4 of a full tile's time, after
@@ -674,10 +702,9 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2
 // the pieces AS INTEGERS and converts once, with the main epilogue's own expression: the G entries are bit-identical to the ones
 // the 17th pair block produced.
 template <int S>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_assemble_i8_tail(
+__device__ __forceinline__ void assemble_i8_tail_body(
     const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int NP, int nks_total, int ks0, int nk, int n_chains, int pb32_0,
-    int ntail, int* __restrict__ Tq, I8Delta dl) {
-  if (dl.skip()) return;
+    int ntail, int* __restrict__ Tq) {
   const int nCB = nCp / I8_BM;
   const int cb = blockIdx.x % nCB, tb = blockIdx.x / nCB;
   const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -697,10 +724,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   });
 }
 template <int S>
-__global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restrict__ Tq, int pieces, int nCp, int ntail, int pb32_0, int accumulate,
-                                                             I8Pairs pr, int n_chains, const int* __restrict__ phase, const int* __restrict__ vbad,
-                                                             int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp, I8Delta dl) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_assemble_i8_tail(
+    const int8_t* __restrict__ Vs, const int8_t* __restrict__ Zs, int nCp, int NPp, int NP, int nks_total, int ks0, int nk, int n_chains, int pb32_0,
+    int ntail, int* __restrict__ Tq, I8Delta dl) {
   if (dl.skip()) return;
+  assemble_i8_tail_body<S>(Vs, Zs, nCp, NPp, NP, nks_total, ks0, nk, n_chains, pb32_0, ntail, Tq);
+}
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_assemble_i8_tail_sel(
+    const int8_t* __restrict__ Vs, size_t vplane, int seff, const int8_t* __restrict__ Zs, int nCp, int NPp, int NP, int nks_total, int ks0, int nk,
+    int n_chains, int pb32_0, int ntail, int* __restrict__ Tq, I8Delta dl) {
+  const int Sp = i8_delta_pick(dl, seff);
+  Vs += (size_t)(seff - Sp) * vplane;
+  if (Sp == 6) assemble_i8_tail_body<6>(Vs, Zs, nCp, NPp, NP, nks_total, ks0, nk, n_chains, pb32_0, ntail, Tq);
+  else if (Sp == 5) assemble_i8_tail_body<5>(Vs, Zs, nCp, NPp, NP, nks_total, ks0, nk, n_chains, pb32_0, ntail, Tq);
+  else assemble_i8_tail_body<4>(Vs, Zs, nCp, NPp, NP, nks_total, ks0, nk, n_chains, pb32_0, ntail, Tq);
+}
+template <int S>
+__device__ __forceinline__ void assemble_i8_tailsum_body(const int* __restrict__ Tq, int pieces, int nCp, int ntail, int pb32_0, int accumulate,
+                                                         const I8Pairs& pr, int n_chains, const int* __restrict__ phase, const int* __restrict__ vbad,
+                                                         int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp, const I8Delta& dl) {
   const int W = 32 * ntail;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(i / W), j = (int)(i % W);
@@ -720,6 +762,22 @@ __global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restri
   else if ((accumulate & 2) && !(dl.rebase && dl.rebase[c])) gv += dl.Gbase ? dl.Gbase[(size_t)c * DP * DP + a * DP + b] : *gp;
   else if (a == b) gv += inv_alpha;
   *gp = gv;
+}
+template <int S>
+__global__ __launch_bounds__(256) void k_assemble_i8_tailsum(const int* __restrict__ Tq, int pieces, int nCp, int ntail, int pb32_0, int accumulate,
+                                                             I8Pairs pr, int n_chains, const int* __restrict__ phase, const int* __restrict__ vbad,
+                                                             int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp, I8Delta dl) {
+  if (dl.skip()) return;
+  assemble_i8_tailsum_body<S>(Tq, pieces, nCp, ntail, pb32_0, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, vexp, dl);
+}
+__global__ __launch_bounds__(256) void k_assemble_i8_tailsum_sel(int seff, const int* __restrict__ Tq, int pieces, int nCp, int ntail, int pb32_0, int accumulate,
+                                                                 I8Pairs pr, int n_chains, const int* __restrict__ phase, const int* __restrict__ vbad,
+                                                                 int DP, double inv_alpha, double* __restrict__ Gq, const int* __restrict__ vexp, I8Delta dl) {
+  const int Sp = i8_delta_pick(dl, seff);
+  dl.cscale = __builtin_ldexp(1.0, -8 * (seff - Sp));
+  if (Sp == 6) assemble_i8_tailsum_body<6>(Tq, pieces, nCp, ntail, pb32_0, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, vexp, dl);
+  else if (Sp == 5) assemble_i8_tailsum_body<5>(Tq, pieces, nCp, ntail, pb32_0, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, vexp, dl);
+  else assemble_i8_tailsum_body<4>(Tq, pieces, nCp, ntail, pb32_0, accumulate, pr, n_chains, phase, vbad, DP, inv_alpha, Gq, vexp, dl);
 }
 
 // dst[i] = sum over planes of src[plane][i], in plane order (deterministic)

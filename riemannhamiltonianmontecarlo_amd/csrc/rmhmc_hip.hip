@@ -351,6 +351,36 @@ void launch_assemble_i8_t(rmhmc_ctx* ctx, Group& g, const double* v, hipStream_t
     }
   }
 }
+// Delta assembly (use_delta: S = 6, the 8-wave tile, no k-split planes): one launch each of the main tiles, the ragged pair block's tiles and their
+// sum; the kernels pick the slice count the difference needs from *dmax themselves (k_assemble_i8_sel).  seff 6: full accuracy; 5: inner iterate
+void launch_assemble_i8_delta(rmhmc_ctx* ctx, Group& g, hipStream_t st, int seff) {
+  constexpr int WN = 4, TN = 1;
+  const size_t vplane = (size_t)ctx->i8_nks * g.nCp * 32;
+  const I8Delta dl{g.dmax, g.rebase, 1.0, 0, 0, ctx->big ? g.Gbase : nullptr};
+  const int nCB = g.nCp / I8_BM, nPB = ctx->pairs.NPp / (32 * TN * WN);
+  constexpr int lds = i8_lds_bytes<6, WN, TN>() > i8_lds_bytes<4, WN, TN>() ? i8_lds_bytes<6, WN, TN>() : i8_lds_bytes<4, WN, TN>();
+  static_assert(lds >= (i8_lds_bytes<5, WN, TN>()), "dynamic LDS of the widest instantiation");
+  const int nPBfull = ctx->pairs.NP / (32 * TN * WN);
+  const bool tail = g.Tq && nPBfull < nPB && (ctx->opt.i8_tail == 1 || (ctx->opt.i8_tail < 0 && (long long)nCB * nPBfull >= 256));
+  const int npb = tail ? nPBfull : nPB;
+  const unsigned nblk_main = (unsigned)(nCB < 8 ? nCB * npb : (nCB + 7) / 8 * 8 * npb);
+  const int pb32_0 = nPBfull * TN * WN, ntail = (ctx->pairs.NP - pb32_0 * 32 + 31) / 32;
+  constexpr int lds_t = i8_lds_bytes<6, 1, 1>() > i8_lds_bytes<4, 1, 1>() ? i8_lds_bytes<6, 1, 1>() : i8_lds_bytes<4, 1, 1>();
+  static_assert(lds_t >= (i8_lds_bytes<5, 1, 1>()), "dynamic LDS of the widest tail instantiation");
+  for (int ks0 = 0; ks0 < ctx->i8_nks; ks0 += ctx->i8_chunk) {
+    const int nk = std::min(ctx->i8_chunk, ctx->i8_nks - ks0);
+    if (nblk_main)
+      hipLaunchKernelGGL((k_assemble_i8_sel<WN, TN>), dim3(nblk_main), dim3(128 * WN), lds, st, g.Vs, vplane, seff, ctx->d_Zs, g.nCp, ctx->i8_nks, ks0, nk,
+                         (ks0 > 0 ? 1 : 0) | 2, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, (size_t)0, g.vexp_d, npb, dl);
+    if (tail) {
+      const int pieces = std::max(1, std::min({g.tail_pieces, nk / 8, (int)(256 / std::max(1, nCB * ntail))}));
+      hipLaunchKernelGGL(k_assemble_i8_tail_sel, dim3((unsigned)(nCB * ntail), (unsigned)pieces), dim3(128), lds_t, st, g.Vs, vplane, seff, ctx->d_Zs,
+                         g.nCp, ctx->pairs.NPp, ctx->pairs.NP, ctx->i8_nks, ks0, nk, g.n, pb32_0, ntail, g.Tq, dl);
+      hipLaunchKernelGGL(k_assemble_i8_tailsum_sel, dim3((unsigned)(((size_t)g.n * 32 * ntail + 255) / 256)), dim3(256), 0, st, seff, g.Tq, pieces, g.nCp, ntail,
+                         pb32_0, (ks0 > 0 ? 1 : 0) | 2, ctx->pairs, g.n, g.ch.phase, g.vbad, ctx->DP, ctx->dd.inv_alpha, g.ch.Gq, g.vexp_d, dl);
+    }
+  }
+}
 // leverage pass of the int8 path: part 0 cuts G^-1 into slices, part 1 is the GEMM (R = c .* h into rv0, v is dead by then)
 template <int S, int WN, int TN>
 void launch_leverage_i8_t(rmhmc_ctx* ctx, Group& g, hipStream_t st, int part) {
@@ -384,18 +414,11 @@ void launch_assemble(rmhmc_ctx* ctx, Group& g, const double* v, bool inner = fal
   if (ctx->i8 && delta && ctx->big)
     launch(ctx, g, HEAVY, "vsplit", [&](hipStream_t st) { launch_assemble_i8_t<6, 4, 1>(ctx, g, v, st, 0, true); });
   if (ctx->i8 && delta && inner) {  // (use_delta_inner: five-slice accuracy)
-    launch(ctx, g, HEAVY, "assemble_i8_inner_delta", [&](hipStream_t st) {
-      launch_assemble_i8_t<5, 4, 1>(ctx, g, v, st, 1, true, 5, 6, 6);
-      launch_assemble_i8_t<4, 4, 1>(ctx, g, v, st, 1, true, 5, 4, 5);
-    });
+    launch(ctx, g, HEAVY, "assemble_i8_inner_delta", [&](hipStream_t st) { launch_assemble_i8_delta(ctx, g, st, 5); });
     return;
   }
   if (ctx->i8 && delta) {  // (use_delta: S = 6, WN = 4)
-    launch(ctx, g, HEAVY, "assemble_i8_delta", [&](hipStream_t st) {
-      launch_assemble_i8_t<6, 4, 1>(ctx, g, v, st, 1, true, 6, 6, 6);
-      launch_assemble_i8_t<5, 4, 1>(ctx, g, v, st, 1, true, 6, 5, 5);
-      launch_assemble_i8_t<4, 4, 1>(ctx, g, v, st, 1, true, 6, 4, 4);
-    });
+    launch(ctx, g, HEAVY, "assemble_i8_delta", [&](hipStream_t st) { launch_assemble_i8_delta(ctx, g, st, 6); });
     return;
   }
   if (ctx->i8) {
@@ -1081,7 +1104,13 @@ int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, 
         auto kfn3 = k_assemble_i8_tail<S_>;
         HIPCK(hipFuncSetAttribute((const void*)kfn3, hipFuncAttributeMaxDynamicSharedMemorySize, (i8_lds_bytes<S_, 1, 1>())));
       });
-      if (S == 6)  // the instantiations of the inner assemblies (launch_assemble) and of the delta assembly
+      if (S == 6) {  // the one-launch delta assembly (launch_assemble_i8_delta): dynamic LDS of its widest instantiation
+        constexpr int ld = i8_lds_bytes<6, 4, 1>() > i8_lds_bytes<4, 4, 1>() ? i8_lds_bytes<6, 4, 1>() : i8_lds_bytes<4, 4, 1>();
+        constexpr int ldt = i8_lds_bytes<6, 1, 1>() > i8_lds_bytes<4, 1, 1>() ? i8_lds_bytes<6, 1, 1>() : i8_lds_bytes<4, 1, 1>();
+        HIPCK(hipFuncSetAttribute((const void*)k_assemble_i8_sel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ld));
+        HIPCK(hipFuncSetAttribute((const void*)k_assemble_i8_tail_sel, hipFuncAttributeMaxDynamicSharedMemorySize, ldt));
+      }
+      if (S == 6)  // the instantiations of the inner assemblies (launch_assemble)
         for (int sv = S - 2; sv < S; ++sv)
           I8_SWITCH_S(sv, {
             auto kfn = k_assemble_i8<S_, WN_, TN_>;

@@ -22,7 +22,7 @@ def short(name):
     return name[:60]
 
 
-# The delta assembly launches the S' = 6, 5, 4 instantiations of k_assemble_i8 / _tail / _tailsum and all but one return at once
+# (Profiles up to the middle of round 3:) the delta assembly launched the S' = 6, 5, 4 instantiations of k_assemble_i8 / _tail / _tailsum and all but one returned at once
 # (a few us, no memory traffic): those dispatches are counted apart, the averages are over the dispatches that did the work.
 def is_gemm(name):
     return "k_assemble_i8" in name
@@ -150,6 +150,14 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
         if f > 0:
             tr["assemble_i8_x%d_fetch_raw_kib" % S] = f; tr["assemble_i8_x%d_write_raw_kib" % S] = w
             tr["assemble_i8_x%d_bytes_per_launch" % S] = (2.0 * f + w) * 1024.0
+    # the one-launch delta assembly (whatever slice count its launches picked: 4 at stationarity)
+    f = w = 0.0
+    for part in ("k_assemble_i8_sel<4, 1>", "k_assemble_i8_tail_sel", "k_assemble_i8_tailsum_sel"):
+        f += summary["FETCH_SIZE"].get(part, {}).get("avg_raw_kib", 0.0)
+        w += summary["WRITE_SIZE"].get(part, {}).get("avg_raw_kib", 0.0)
+    if f > 0:
+        tr["assemble_i8_delta_fetch_raw_kib"] = f; tr["assemble_i8_delta_write_raw_kib"] = w
+        tr["assemble_i8_delta_bytes_per_launch"] = (2.0 * f + w) * 1024.0
     for name in ("k_assemble<4>", "k_assemble<3>", "k_assemble<2>", "k_assemble<1>"):
         if name in summary["FETCH_SIZE"]:
             tr["assemble_bytes_per_launch"] = (2.0 * summary["FETCH_SIZE"][name]["avg_raw_kib"] + summary["WRITE_SIZE"].get(name, {}).get("avg_raw_kib", 0.0)) * 1024.0
