@@ -847,56 +847,77 @@ __global__ __launch_bounds__(256) void k_ztsplit(const double* __restrict__ Xr, 
 template <int S>
 __global__ __launch_bounds__(256) void k_qsplit(const double* __restrict__ Ginv, int DP, I8Pairs pr, const int* __restrict__ phase, int nkp,
                                                 int nCp, int8_t* __restrict__ Qs, double* __restrict__ qscale) {
-  __shared__ double red[256];
-  __shared__ int sh_e;
+  // One pass over the chain's G^-1: every thread keeps the (at most QMAX x 4) equilibrated entries of its quads in registers between the
+  // maximum and the slicing (it used to gather them twice, with a nine-barrier tree reduction in between: 167 us per launch at config 3,
+  // 83 % of the wave cycles in s_waitcnt).  More than QMAX x 256 quads (D > 64 never comes here with that many): the second gather again.
+  constexpr int QMAX = 3;
+  __shared__ double red[4];
   const int c = blockIdx.x, t = threadIdx.x;
   if (phase[c] != 1) return;
   const double* __restrict__ Gi = Ginv + (size_t)c * DP * DP;
+  const int nq = nkp * 8;
+  double qv[QMAX][4];
   double m = 0.0;
   bool bad = false;
-  for (int p = t; p < pr.NP; p += 256) {
+  // entry p of the equilibrated inverse, off-diagonal entries doubled (they count twice in x' G^-1 x); mag: its size before the doubling
+  auto entry = [&](int p, double& mag) {
+    mag = 0.0;
+    if (p >= pr.NP) return 0.0;
     const int a = pr.pa[p], b = pr.pb[p];
     const double q = ldexp(Gi[a * DP + b], pr.cexp[a] + pr.cexp[b]);
-    bad |= !(fabs(q) < 1e300);
-    m = fmax(m, fabs(q));
-  }
-  red[t] = bad ? __builtin_inf() : m;
+    mag = fabs(q);
+    return a == b ? q : 2.0 * q;
+  };
+#pragma unroll
+  for (int i = 0; i < QMAX; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q4 = t + 256 * i;
+      double mag = 0.0;
+      qv[i][k] = q4 < nq ? entry(4 * q4 + k, mag) : 0.0;
+      bad |= !(mag < 1e300);
+      m = fmax(m, mag);
+    }
+  for (int q4 = t + 256 * QMAX; q4 < nq; q4 += 256)
+    for (int k = 0; k < 4; ++k) {
+      double mag;
+      (void)entry(4 * q4 + k, mag);
+      bad |= !(mag < 1e300);
+      m = fmax(m, mag);
+    }
+  if (bad) m = __builtin_inf();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if ((t & 63) == 0) red[t >> 6] = m;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (t < s) red[t] = fmax(red[t], red[t + s]);
-    __syncthreads();
-  }
-  if (t == 0) {
-    int e = 0;
-    const double mx = 2.0 * red[0];  // off-diagonal entries count twice
-    const bool ok = mx < 1e300;
-    if (ok && mx > 0.0) (void)frexp(mx, &e);
-    sh_e = e;
-    qscale[c] = ok ? ldexp(1.0, e - 12) : __builtin_nan("");
-  }
-  __syncthreads();
-  const int shf = 8 * S - 2 - sh_e;
-  const bool ok = red[0] < 1e300;
-  for (int q4 = t; q4 < nkp * 8; q4 += 256) {
+  const double mx = 2.0 * fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));  // off-diagonal entries count twice (as before: the same scale, the same digits)
+  const bool ok = mx < 1e300;
+  int e = 0;
+  if (ok && mx > 0.0) (void)frexp(mx, &e);
+  if (t == 0) qscale[c] = ok ? ldexp(1.0, e - 12) : __builtin_nan("");
+  const int shf = 8 * S - 2 - e;
+  auto put = [&](int q4, const double (&q)[4]) {
     int w[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) w[s] = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int p = 4 * q4 + k;
-      double q = 0.0;
-      if (ok && p < pr.NP) {
-        const int a = pr.pa[p], b = pr.pb[p];
-        q = ldexp(Gi[a * DP + b], pr.cexp[a] + pr.cexp[b] + (a == b ? 0 : 1));
-      }
       int d[S];
-      split_digits<S>((long long)rint(ldexp(q, shf)), d);
+      split_digits<S>((long long)rint(ldexp(ok ? q[k] : 0.0, shf)), d);
 #pragma unroll
       for (int s = 0; s < S; ++s) w[s] |= (d[S - 1 - s] & 0xFF) << (8 * k);
     }
     const int kp = q4 >> 3, k4 = q4 & 7;
 #pragma unroll
     for (int s = 0; s < S; ++s) *(int*)(Qs + (((size_t)s * nkp + kp) * nCp + c) * 32 + 4 * k4) = w[s];
+  };
+#pragma unroll
+  for (int i = 0; i < QMAX; ++i)
+    if (t + 256 * i < nq) put(t + 256 * i, qv[i]);
+  for (int q4 = t + 256 * QMAX; q4 < nq; q4 += 256) {
+    double mag;
+    const double q[4] = {entry(4 * q4, mag), entry(4 * q4 + 1, mag), entry(4 * q4 + 2, mag), entry(4 * q4 + 3, mag)};
+    put(q4, q);
   }
 }
 
