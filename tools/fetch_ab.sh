@@ -16,7 +16,7 @@ f = glob.glob(O + "/fetch_%s/**/*counter_collection.csv" % v, recursive=True)[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    if "k_assemble_i8<" in n or "k_leverage_i8<" in n:
+    if "k_assemble_i8" in n and "tail" not in n or "k_leverage_i8<" in n:
         agg[n.split("(")[0][-40:]].append(float(r["Counter_Value"]))
 for n, vals in sorted(agg.items()):
     big = [x for x in vals if x > 0.02 * max(vals)]
@@ -25,7 +25,7 @@ t = glob.glob(O + "/trace_%s/**/*kernel_trace.csv" % v, recursive=True)[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(t)):
     n = r["Kernel_Name"]
-    if "k_assemble_i8<" in n or "k_leverage_i8<" in n:
+    if "k_assemble_i8" in n and "tail" not in n or "k_leverage_i8<" in n:
         agg[n.split("(")[0][-40:]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for n, vals in sorted(agg.items()):
     big = [x for x in vals if x > 0.2 * max(vals)]
