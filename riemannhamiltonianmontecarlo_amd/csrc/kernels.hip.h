@@ -1427,13 +1427,13 @@ __device__ __forceinline__ void load_mat_lds(double* A, const double* __restrict
 // factor already stored in the trajectory record, so u = u0 and Pw^1 = w + tau*eps*u0.
 // upd_nsplit > 0: the last momentum fixed-point update p = p + tau eps/2 (grad - tr/2 + q/2) (rmhmc.py:108,110; k_mom_update with final = 1)
 // is done here first, q summed from upd_nsplit row-split planes
+// u0 = G^-1 p (rmhmc.py:113) as a product with the stored inverse - k_ginv_matvec's loop, bound by reading the matrix once: 66 us - instead of
+// two triangular solves with the stored factor (128 dependent v_readlane steps per chain: 113 us); G^-1 = W'W is the same factor's inverse
 __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, double eps, int upd_nsplit = 0) {
-  __shared__ __attribute__((aligned(16))) double A[RM_PK_DOUBLES];
+  __shared__ double A[64];
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c == 0 && lane == 0 && ch.stale_list) *ch.stale_count = 0;  // (k_crestore has consumed the list; k_iter_end appends at the end of the step)
   if (ch.phase[c] != 1) return;
-  load_mat_lds<true>(A, ch.trj.L + (size_t)c * DP * DP, D, DP, lane);
-  const double rdiag = (lane < D) ? 1.0 / A[rm_row<true>(lane) + lane] : 1.0;
   double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
   if (upd_nsplit > 0 && lane < D) {
     const size_t o = (size_t)c * DP + lane;
@@ -1442,7 +1442,12 @@ __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, doub
     pb = pb + (ch.tau[c] * eps * 0.5) * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
     ch.p[o] = pb;
   }
-  const double u0 = cholsolve_lds<true>(A, D, lane, pb, rdiag);
+  double u0 = 0.0;
+  A[lane] = pb;
+  __builtin_amdgcn_wave_barrier();
+  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  for (int j = 0; j < D; ++j)
+    if (lane < D) u0 = fma(Gi[j * DP + lane], A[j], u0);  // symmetric: row j read coalesced
   if (lane < D) {
     ch.u0[(size_t)c * DP + lane] = u0;
     ch.wq[(size_t)c * DP + lane] = ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * eps * u0;
