@@ -1803,6 +1803,21 @@ __device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, 
 
 // 0.5 * p' Ginv p for the chain's vector ps[0..D) in LDS
 __device__ __forceinline__ double half_quadform(const double* __restrict__ Gi, int D, int DP, int lane, const double* ps) {
+  if (D <= 64) {
+    // lane = dimension; sixteen rows in flight at a time (the loop below is one load - one wait per row: in k_iter_begin / k_iter_end, where only
+    // the chains at a transition boundary work, 64 serial round trips were most of the kernels' 110 / 88 us).  Same sums in the same order.
+    const bool in = lane < D;
+    double y = 0.0;
+    for (int j0 = 0; j0 < D; j0 += 16) {
+      double g[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) g[q] = (in && j0 + q < D) ? Gi[(size_t)(j0 + q) * DP + lane] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (in && j0 + q < D) y = fma(g[q], ps[j0 + q], y);
+    }
+    return 0.5 * wave_sum(in ? fma(y, ps[lane], 0.0) : 0.0);
+  }
   double y[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < D; ++j) {
     const double pj = ps[j];
@@ -1863,7 +1878,27 @@ __device__ __forceinline__ void iter_begin_dev(int D, int DP, const Chains& ch, 
   // momentum p = L' z (reference, rmhmc.py:60,80) or L z (corrected)
   const double* __restrict__ Lc = ch.cur.L + (size_t)c * DP * DP;
   double p[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
-  if (ip.flags & 1u) {
+  if (D <= 64) {  // lane = dimension, sixteen loads in flight (as half_quadform); the same sums in the same order as the loops below
+    const int d = lane;
+    double acc = 0.0;
+    for (int j0 = 0; j0 < D; j0 += 16) {
+      double l[16];
+      if (ip.flags & 1u) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) l[q] = (j0 + q < D && d <= j0 + q) ? Lc[(size_t)(j0 + q) * DP + d] : 0.0;   // L' z: column d of row j0 + q
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (j0 + q < D && d <= j0 + q) acc = fma(l[q], zs[j0 + q], acc);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) l[q] = (d < D && j0 + q <= d) ? Lc[(size_t)d * DP + j0 + q] : 0.0;            // L z: the lane's own row
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (d < D && j0 + q <= d) acc = fma(l[q], zs[j0 + q], acc);
+      }
+    }
+    p[0] = acc;
+  } else if (ip.flags & 1u) {
     for (int i = 0; i < D; ++i) {
       const double zi = zs[i];
 #pragma unroll
