@@ -1780,13 +1780,23 @@ __device__ __forceinline__ void copy_rec(const Rec& dst, const Rec& src, int c, 
   const size_t m = (size_t)c * DP * DP;
   for (int d = lane; d < D; d += 64) {
     int i = 0;
-    for (; i + 8 <= D; i += 8) {  // eight rows of both matrices in flight (the copy is latency bound: one wavefront per chain)
+    for (; i + 16 <= D; i += 16) {  // sixteen rows of both matrices in flight (the copy is latency bound: one wavefront per chain)
+      double a[16], b[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a[q] = lowerL && d > i + 15 ? 0.0 : src.L[m + (i + q) * DP + d]; b[q] = src.Ginv[m + (i + q) * DP + d]; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (!(lowerL && d > i + 15)) dst.L[m + (i + q) * DP + d] = a[q];   // (a lower factor: zero above the diagonal on both sides, always)
+        dst.Ginv[m + (i + q) * DP + d] = b[q];
+      }
+    }
+    for (; i + 8 <= D; i += 8) {
       double a[8], b[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) { a[q] = lowerL && d > i + 7 ? 0.0 : src.L[m + (i + q) * DP + d]; b[q] = src.Ginv[m + (i + q) * DP + d]; }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        if (!(lowerL && d > i + 7)) dst.L[m + (i + q) * DP + d] = a[q];   // (a lower factor: zero above the diagonal on both sides, always)
+        if (!(lowerL && d > i + 7)) dst.L[m + (i + q) * DP + d] = a[q];
         dst.Ginv[m + (i + q) * DP + d] = b[q];
       }
     }
