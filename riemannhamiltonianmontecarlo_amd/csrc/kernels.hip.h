@@ -1434,20 +1434,39 @@ __global__ __launch_bounds__(64) void k_pos_first(int D, int DP, Chains ch, doub
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c == 0 && lane == 0 && ch.stale_list) *ch.stale_count = 0;  // (k_crestore has consumed the list; k_iter_end appends at the end of the step)
   if (ch.phase[c] != 1) return;
-  double pb = (lane < D) ? ch.p[(size_t)c * DP + lane] : 0.0;
-  if (upd_nsplit > 0 && lane < D) {
+  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  const bool in = lane < D;
+  double g[16];  // sixteen matrix rows in flight, the first sixteen requested before the partial sums (as k_mom_update_matvec)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) g[q] = (in && q < D) ? Gi[q * DP + lane] : 0.0;  // symmetric: row j read coalesced
+  double pb = in ? ch.p[(size_t)c * DP + lane] : 0.0;
+  if (upd_nsplit > 0 && in) {
     const size_t o = (size_t)c * DP + lane;
     double q = 0.0;
-    for (int sp = 0; sp < upd_nsplit; ++sp) q += ch.qpart[((size_t)sp * ch.n + c) * DP + lane];
+    for (int s0 = 0; s0 < upd_nsplit; s0 += 16) {
+      double t[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t[k] = (s0 + k < upd_nsplit) ? ch.qpart[((size_t)(s0 + k) * ch.n + c) * DP + lane] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (s0 + k < upd_nsplit) q += t[k];
+    }
     pb = pb + (ch.tau[c] * eps * 0.5) * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
     ch.p[o] = pb;
   }
   double u0 = 0.0;
   A[lane] = pb;
   __builtin_amdgcn_wave_barrier();
-  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
-  for (int j = 0; j < D; ++j)
-    if (lane < D) u0 = fma(Gi[j * DP + lane], A[j], u0);  // symmetric: row j read coalesced
+  for (int j0 = 0; j0 < D; j0 += 16) {
+    double gn[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gn[q] = (in && j0 + 16 + q < D) ? Gi[(j0 + 16 + q) * DP + lane] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (in && j0 + q < D) u0 = fma(g[q], A[j0 + q], u0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = gn[q];
+  }
   if (lane < D) {
     ch.u0[(size_t)c * DP + lane] = u0;
     ch.wq[(size_t)c * DP + lane] = ch.trj.w[(size_t)c * DP + lane] + ch.tau[c] * eps * u0;
@@ -1667,6 +1686,21 @@ __global__ __launch_bounds__(64) void k_ginv_matvec(int D, int DP, Chains ch, co
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 1) return;
   const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  if (D <= 64) {  // lane = dimension, sixteen rows in flight (as k_mom_update_matvec); the same sums in the same order as the loop below
+    const bool in = lane < D;
+    const double sv = in ? src[(size_t)c * DP + lane] : 0.0;
+    double u0 = 0.0;
+    for (int j0 = 0; j0 < D; j0 += 16) {
+      double g[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) g[q] = (in && j0 + q < D) ? Gi[(j0 + q) * DP + lane] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (in && j0 + q < D) u0 = fma(g[q], rdlane(sv, j0 + q), u0);
+    }
+    if (in) ch.uq[(size_t)c * DP + lane] = u0;
+    return;
+  }
   double u[RM_DCH] = {0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < D; ++j) {
     const double sj = src[(size_t)c * DP + j];
@@ -1701,20 +1735,39 @@ __global__ __launch_bounds__(64) void k_mom_update_matvec(int D, int DP, Chains 
   const int c = blockIdx.x, lane = threadIdx.x;
   if (ch.phase[c] != 1) return;
   const size_t o = (size_t)c * DP + lane;
+  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
+  const bool in = lane < D;
+  // sixteen matrix rows in flight at a time, the first sixteen requested before the partial sums are (every chain's wavefront is resident at
+  // once here, so the launch lasts as long as ONE wavefront's chain of round trips: it was one per row and one per partial)
+  double g[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) g[q] = (in && q < D) ? Gi[q * DP + lane] : 0.0;  // symmetric: row j read coalesced
   double pm = 0.0;
-  if (lane < D) {
+  if (in) {
     double q = 0.0;
-    for (int s = 0; s < nsplit; ++s) q += ch.qpart[((size_t)s * ch.n + c) * DP + lane];
+    for (int s0 = 0; s0 < nsplit; s0 += 16) {
+      double t[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t[k] = (s0 + k < nsplit) ? ch.qpart[((size_t)(s0 + k) * ch.n + c) * DP + lane] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (s0 + k < nsplit) q += t[k];
+    }
     pm = ch.p[o] + (ch.tau[c] * eps * 0.5) * (ch.trj.grad[o] - 0.5 * ch.trj.tr[o] + 0.5 * q);
     ch.PM[o] = pm;
   }
-  const double* __restrict__ Gi = ch.trj.Ginv + (size_t)c * DP * DP;
   double u = 0.0;
-  for (int j = 0; j < D; ++j) {
-    const double gj = (lane < D) ? Gi[j * DP + lane] : 0.0;  // symmetric: row j read coalesced
-    u = fma(gj, rdlane(pm, j), u);
+  for (int j0 = 0; j0 < D; j0 += 16) {
+    double gn[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gn[q] = (in && j0 + 16 + q < D) ? Gi[(j0 + 16 + q) * DP + lane] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (j0 + q < D) u = fma(g[q], rdlane(pm, j0 + q), u);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = gn[q];
   }
-  if (lane < D) ch.uq[o] = u;
+  if (in) ch.uq[o] = u;
 }
 
 // explicit momentum half step at the new point (rmhmc.py:163) + step bookkeeping
