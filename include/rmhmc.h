@@ -128,6 +128,7 @@ int rmhmc_create(rmhmc_ctx **out, int32_t device_id, int64_t M, int32_t D,
  *   hmc_traj_maxn [create] -1  largest batch for the one-launch HMC trajectory (-1: the built-in rule)
  *   fsplit   [create] 0        row ranges per chain of the fp64 assembly of small batches (0: chosen from the batch size)
  *   nsplit_max [create] 64     cap on the row splits of the 16-chains-per-wavefront passes
+ *   nsplit_waves [create] -1   wavefronts per launch those row splits aim at (-1: 2048 for D <= 64, 6144 for the blocked large-D passes)
  *   i8_tail  [create] -1       int8 path: ragged last pair block as tiles of its own: -1 when it pays, 0 never, 1 always
  *   i8_delta [create] 1        int8 path, 6 slices: the metric at the end of a leapfrog step as G(last iterate) + the assembly
  *                              of the v differences (4 slices)

@@ -62,7 +62,7 @@ enum Cls { HEAVY = 0, LIGHT = 1 };  // (documentation of a launch's kind: matrix
 // Tuning options (include/rmhmc.h: rmhmc_create_opts / rmhmc_set_option).  The library reads no environment variables.
 struct Options {
   int64_t graph = 1, sorted = 1, inflight = 32, cdyn = 1, crestore = 1, i8_force_rebase = 0;                 // run time
-  int64_t ccache = 1, medium = 1, fused = 1, hmc_traj_maxn = -1, fsplit = 0, nsplit_max = 64, i8_tail = -1,   // create time
+  int64_t ccache = 1, medium = 1, fused = 1, hmc_traj_maxn = -1, fsplit = 0, nsplit_max = 64, nsplit_waves = -1, i8_tail = -1,   // create time
           i8_delta = 1, i8_delta_inner = 1;
 };
 struct OptionDesc { const char* key; int64_t Options::*slot; bool create_only; int64_t lo, hi; };
@@ -79,6 +79,7 @@ const OptionDesc kOptions[] = {
     {"hmc_traj_maxn", &Options::hmc_traj_maxn, true, -1, (int64_t)1 << 40},
     {"fsplit", &Options::fsplit, true, 0, 64},
     {"nsplit_max", &Options::nsplit_max, true, 1, 1 << 20},
+    {"nsplit_waves", &Options::nsplit_waves, true, -1, 1 << 20},
     {"i8_tail", &Options::i8_tail, true, -1, 1},
     {"i8_delta", &Options::i8_delta, true, 0, 1},
     {"i8_delta_inner", &Options::i8_delta_inner, true, 0, 1},
@@ -1006,9 +1007,13 @@ int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, 
       Group& g = ctx->groups[0];
       g.off = 0;
       g.n = (int)n_chains;
-      // row splits of the 16-chains-per-wave passes: aim at >= ~6000 waves per launch
+      // row splits of the 16-chains-per-wave passes (option nsplit_waves).  D <= 64: ~2048 wavefronts per launch = ONE round of two
+      // four-wave workgroups per CU - measured against the 6144 of rounds 1-2 (three rounds) on one box, interleaved: 14.73-14.92
+      // against 14.99-15.08 ms per step at config 3, +2.7 % steps/s at 4096 chains, +6 % at 2048 and 1024 (fewer partial sums to write and
+      // to add up, fewer prologues); the blocked large-D passes keep 6144 (config 5: 472.8 against 475.4 ms per step).
       const long long cgroups = (g.n + 15) / 16, nb16 = ctx->Mp / 16;
-      long long ns = (6144 + cgroups - 1) / cgroups;
+      const long long target = ctx->opt.nsplit_waves > 0 ? ctx->opt.nsplit_waves : (ctx->big ? 6144 : 2048);
+      long long ns = (target + cgroups - 1) / cgroups;
       if (ns < 1) ns = 1;
       if (ns > nb16) ns = nb16;
       // ... but no more than 64 splits (option nsplit_max): the consumers sum the partials serially.  (Round 1 kept up to Mp/16 splits for
