@@ -654,13 +654,13 @@ void step_phases(rmhmc_ctx* ctx, std::vector<Phase>& ph) {
     ph.push_back([=](Group& g) {
       if (!g.ctile || !g.ch.stale_list) return;
       launch(ctx, g, HEAVY, "mompass", [&](hipStream_t st) {
-        // row pieces of this kernel's own.  Measured at config 3 (~300 chains = 19 wavefront groups per step): 16 pieces 86 us, 64 pieces 94,
-        // 314 pieces (one block per wavefront) 149 - a wavefront alone on its SIMD takes ~4.3 us per 32-row block (load - product - exp
-        // latencies with nothing to hide them), and every workgroup that only reads the count and returns costs ~15-30 ns.
-        const int rsplit = std::max(1, std::min(16, ctx->Mp / 32 / 4));
-        // (room for 2048 rejected chains; any beyond stay flagged and k_mompass<.., 3> recomputes their wavefronts as before.  A grid for
-        //  the whole batch spent 100 us launching 8192 workgroups of which ~5 % had work.)
-        dim3 grid((unsigned)std::min((g.n + 63) / 64, 32), (unsigned)rsplit);
+        // row pieces of this kernel's own, and a SMALL grid whose wavefronts walk the list (8 x 64 chains at a time): a wavefront alone on its
+        // SIMD takes ~4.3 us per 32-row block (load - product - exp latencies with nothing to hide them), and workgroups that only read the
+        // count and return are not free either.  Measured at config 3 (~300 listed chains = 19 wavefront groups per step, one box,
+        // tools/crs_sweep.sh): grid 32 x 16 (round 2: room for 2048 chains, the rest left to k_mompass<.., 3>) 75.6 us, 8 x 16 43, 8 x 32 29.3,
+        // 8 x 64 31.9, 4 x 64 28.6, 2 x 128 34.1.
+        const int rsplit = std::max(1, std::min(32, ctx->Mp / 32 / 4));
+        dim3 grid((unsigned)std::min((g.n + 63) / 64, 8), (unsigned)rsplit);
         NB_SWITCH(ctx, hipLaunchKernelGGL((k_crestore<NB_>), grid, dim3(256), 0, st, ctx->dd, g.n, g.ch.phase, g.ch.trj.w, g.ctile, g.ch.cstale,
                                           g.ch.stale_list, g.ch.stale_count));
         // (the count is reset by k_pos_first, later in the step)
