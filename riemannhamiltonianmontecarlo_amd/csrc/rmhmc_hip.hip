@@ -1162,8 +1162,9 @@ int rmhmc_create_opts(rmhmc_ctx** out, int32_t device_id, int64_t M, int32_t D, 
       }
     }
     {  // plain HMC in small batches: one launch per trajectory (option medium = 0 disables it too)
-      // any batch for short data sets (rows in registers; australian, 8192 chains: 107 M leapfrog-steps/s vs 76 M generic, 2048
-      // chains 90 M vs 27 M, tools/bench_hmc_batch.py), small batches otherwise
+      // any batch for short data sets (rows in registers; australian, tools/bench_hmc_batch.py: 2048 chains 89 M leapfrog-steps/s vs 39 M
+      // generic, 512 chains 59 M vs 9 M; at 8192 chains the generic path has caught up since its row passes run in one round of
+      // workgroups - 107 M vs 114 M), small batches otherwise
       long long maxn = ctx->Mp <= 1024 ? (1ll << 40) : 512;
       if (ctx->opt.hmc_traj_maxn >= 0) maxn = ctx->opt.hmc_traj_maxn;
       ctx->hmc_traj = ctx->opt.medium && !ctx->big && D <= 32 && n_chains <= maxn;
