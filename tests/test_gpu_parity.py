@@ -644,6 +644,27 @@ def test_first_momentum_pass_reuses_c_tiles_bit_identically(hip, flags):
         assert np.array_equal(x, y)
 
 
+def test_crestore_walks_a_list_longer_than_its_grid(hip):
+    """k_crestore is a small grid (8 x 64 chains per sweep) whose wavefronts walk the list of chains that have just rejected: with a step size that
+    rejects almost everything and 4096 chains the list is several sweeps long in every step.  Same bits as the pass that recomputes c itself."""
+    M, D, n = 2000, 40, 4096
+    XX, t = synthetic_logreg(M, D, 3)
+
+    def run(crestore):
+        with hip.context(M, D, n, flags=0, options={"medium": 0, "fused": 0}) as ctx:
+            ctx.set_data(XX, t)
+            ctx.set_option("crestore", crestore)
+            ctx.chains_init(seed=5, L=3, eps=1.6, K=4)
+            ctx.chains_run(24)
+            return ctx.chains_state()
+
+    a, b = run(1), run(0)
+    iters, acc = a[1], a[2]
+    assert iters.sum() - acc.sum() > 20 * 512          # far more rejections than one sweep of the grid holds, on average per step
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("flags", [0, _capi.int8_metric_flags(6)])
 def test_log_joint_terms_saturate_like_the_reference(hip, oracle, flags):
     """k_rowpass<RP_F> derives log(1 + e^f) and e^f / (1 + e^f) from p (softplus_sigmoid): where e^f overflows the reference gets
